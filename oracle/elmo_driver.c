@@ -1,0 +1,384 @@
+/*
+ * elmo_driver.c - oracle state container and restatement of the reference's L3 dispatch wrappers
+ * (driver/kokkos/*_kokkos.cc).  TEST INFRASTRUCTURE - see elm_oracle.h.
+ *
+ * Each elmo_<wrapper>() does what the reference wrapper's lambda does for column idx: same L2 call
+ * order, same argument wiring (including the quirks: S.forc_tbot passed as forc_t, S.zsoi/S.zisoi as
+ * z/zi, wrapper-local fabd_sun/fabd_sha, qflx_irrig hard-wired 0), with the wrapper's zero-filled
+ * ViewD1(ncols) temporaries as zero-initialised locals.
+ */
+#include "elm_oracle.h"
+#include "elmo_const.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* registry                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+#define KIND_D 0
+#define KIND_I 1
+#define KIND_B 2
+
+typedef struct {
+  const char *name;
+  int kind;
+  int nlev;
+  size_t offset;
+} field_desc;
+
+#include <stddef.h>
+static const field_desc g_fields[] = {
+#define ELMO_DESC(name, kind, nlev) {#name, KIND_##kind, nlev, offsetof(elmo_state, name)},
+    ELMO_FIELDS(ELMO_DESC)
+#undef ELMO_DESC
+};
+enum { NFIELDS = sizeof(g_fields) / sizeof(g_fields[0]) };
+
+static size_t kind_size(int kind) { return kind == KIND_D ? sizeof(double) : (kind == KIND_I ? sizeof(int) : 1); }
+
+elmo_state *elmo_create(int64_t ncols)
+{
+  elmo_state *S = (elmo_state *)calloc(1, sizeof(elmo_state));
+  if (!S) return NULL;
+  S->ncols = ncols;
+  /* LandType() defaults (land_data.h:38) and ELMState defaults (elm_state.h:223-224) */
+  S->land.ltype = 1;
+  S->land.ctype = 0;
+  S->land.vtype = 2;
+  S->land.urbpoi = 0;
+  S->land.lakpoi = 0;
+  S->dewmx = 0.1;
+  S->oldfflag = 1;
+  for (int i = 0; i < NFIELDS; i++) {
+    void *p = calloc((size_t)(ncols > 0 ? ncols : 1) * g_fields[i].nlev, kind_size(g_fields[i].kind));
+    if (!p) {
+      elmo_destroy(S);
+      return NULL;
+    }
+    *(void **)((char *)S + g_fields[i].offset) = p;
+  }
+  S->err_flags = (uint32_t *)calloc((size_t)(ncols > 0 ? ncols : 1), sizeof(uint32_t));
+  return S;
+}
+
+void elmo_destroy(elmo_state *S)
+{
+  if (!S) return;
+  for (int i = 0; i < NFIELDS; i++) free(*(void **)((char *)S + g_fields[i].offset));
+  free(S->err_flags);
+  free(S);
+}
+
+int elmo_num_fields(void) { return NFIELDS; }
+const char *elmo_field_name(int i) { return (i >= 0 && i < NFIELDS) ? g_fields[i].name : NULL; }
+
+void *elmo_field_ptr(elmo_state *S, const char *name, int *nlev, int *kind)
+{
+  if (strcmp(name, "err_flags") == 0) {
+    if (nlev) *nlev = 1;
+    if (kind) *kind = KIND_I;
+    return S->err_flags;
+  }
+  for (int i = 0; i < NFIELDS; i++) {
+    if (strcmp(name, g_fields[i].name) == 0) {
+      if (nlev) *nlev = g_fields[i].nlev;
+      if (kind) *kind = g_fields[i].kind;
+      return *(void **)((char *)S + g_fields[i].offset);
+    }
+  }
+  return NULL;
+}
+
+elmo_snicar *elmo_snicar_ptr(elmo_state *S) { return &S->snicar; }
+elmo_pft_psn *elmo_pft_psn_ptr(elmo_state *S) { return S->pft_psn; }
+elmo_pft_alb *elmo_pft_alb_ptr(elmo_state *S) { return S->pft_alb; }
+double *elmo_z0mr_ptr(elmo_state *S) { return S->z0mr; }
+double *elmo_displar_ptr(elmo_state *S) { return S->displar; }
+double *elmo_albsat_ptr(elmo_state *S) { return &S->albsat[0][0]; }
+double *elmo_albdry_ptr(elmo_state *S) { return &S->albdry[0][0]; }
+
+void elmo_set_scalars(elmo_state *S, int ltype, int ctype, int vtype, int urbpoi, int lakpoi, double dewmx,
+                      int oldfflag, double dayl, double max_dayl)
+{
+  S->land.ltype = ltype;
+  S->land.ctype = ctype;
+  S->land.vtype = vtype;
+  S->land.urbpoi = urbpoi;
+  S->land.lakpoi = lakpoi;
+  S->dewmx = dewmx;
+  S->oldfflag = oldfflag;
+  S->dayl = dayl;
+  S->max_dayl = max_dayl;
+}
+
+void elmo_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+int elmo_get_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* wrappers                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+#define LV(f, n) (S->f + (size_t)c * (n))
+
+/* canopy_hydrology_kokkos.cc:98-112 */
+void elmo_frac_wet(elmo_state *S)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    elmo_ch_fraction_wet(&S->land, S->frac_veg_nosno[c], S->dewmx, S->elai[c], S->esai[c], S->h2ocan[c], &S->fwet[c],
+                         &S->fdry[c]);
+  }
+}
+
+/* canopy_hydrology_kokkos.cc:7-95 */
+void elmo_canopy_hydrology(elmo_state *S, double dt)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double qflx_irrig = 0.0; /* hardwired (:24) */
+    double qflx_candrip = 0.0, qflx_through_snow = 0.0, qflx_through_rain = 0.0, fracsnow = 0.0, fracrain = 0.0;
+    elmo_ch_interception(&S->land, S->frac_veg_nosno[c], S->forc_rain[c], S->forc_snow[c], S->dewmx, S->elai[c],
+                         S->esai[c], dt, &S->h2ocan[c], &qflx_candrip, &qflx_through_snow, &qflx_through_rain,
+                         &fracsnow, &fracrain);
+    elmo_ch_ground_flux(&S->land, S->do_capsnow[c], S->frac_veg_nosno[c], S->forc_rain[c], S->forc_snow[c], qflx_irrig,
+                        qflx_candrip, qflx_through_snow, qflx_through_rain, fracsnow, fracrain, &S->qflx_snwcp_liq[c],
+                        &S->qflx_snwcp_ice[c], &S->qflx_snow_grnd[c], &S->qflx_rain_grnd[c]);
+    elmo_ch_snow_init(&S->land, dt, S->do_capsnow[c], S->oldfflag, S->forc_tbot[c], S->t_grnd[c], S->qflx_snow_grnd[c],
+                      S->qflx_snow_melt[c], S->n_melt[c], &S->snow_depth[c], &S->h2osno[c], &S->int_snow[c],
+                      LV(swe_old, 5), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(frac_iceold, 20),
+                      &S->snl[c], LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), LV(snw_rds, 5), &S->frac_sno_eff[c],
+                      &S->frac_sno[c]);
+    elmo_ch_fraction_h2osfc(&S->land, S->micro_sigma[c], S->h2osno[c], &S->h2osfc[c], LV(h2osoi_liq, 20),
+                            &S->frac_sno[c], &S->frac_sno_eff[c], &S->frac_h2osfc[c]);
+  }
+}
+
+/* surface_radiation_kokkos.cc:7-97 */
+void elmo_surface_radiation(elmo_state *S)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double trd[2] = {0.0, 0.0}, tri[2] = {0.0, 0.0};
+    elmo_sr_canopy_sunshade_fractions(&S->land, S->nrad[c], S->elai[c], LV(tlai_z, 1), LV(fsun_z, 1),
+                                      LV(forc_solad, 2), LV(forc_solai, 2), LV(fabd_sun_z, 1), LV(fabd_sha_z, 1),
+                                      LV(fabi_sun_z, 1), LV(fabi_sha_z, 1), LV(parsun_z, 1), LV(parsha_z, 1),
+                                      LV(laisun_z, 1), LV(laisha_z, 1), &S->laisun[c], &S->laisha[c]);
+    elmo_sr_initialize_flux(&S->land, &S->sabg_soil[c], &S->sabg_snow[c], &S->sabg[c], &S->sabv[c], &S->fsa[c],
+                            LV(sabg_lyr, 6));
+    elmo_sr_total_absorbed_radiation(&S->land, S->snl[c], LV(ftdd, 2), LV(ftid, 2), LV(ftii, 2), LV(forc_solad, 2),
+                                     LV(forc_solai, 2), LV(fabd, 2), LV(fabi, 2), LV(albsod, 2), LV(albsoi, 2),
+                                     LV(albsnd, 2), LV(albsni, 2), LV(albgrd, 2), LV(albgri, 2), &S->sabv[c],
+                                     &S->fsa[c], &S->sabg[c], &S->sabg_soil[c], &S->sabg_snow[c], trd, tri);
+    S->err_flags[c] |= elmo_sr_layer_absorbed_radiation(&S->land, S->snl[c], S->sabg[c], S->sabg_snow[c],
+                                                         S->snow_depth[c], LV(flx_absdv, 6), LV(flx_absdn, 6),
+                                                         LV(flx_absiv, 6), LV(flx_absin, 6), trd, tri, LV(sabg_lyr, 6));
+    elmo_sr_reflected_radiation(&S->land, LV(albd, 2), LV(albi, 2), LV(forc_solad, 2), LV(forc_solai, 2), &S->fsr[c]);
+  }
+}
+
+/* canopy_temperature_kokkos.cc:6-131 */
+void elmo_canopy_temperature(elmo_state *S)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double qred = 0.0, hr = 0.0, soilalpha = 0.0;
+    elmo_ct_old_ground_temp(&S->land, S->t_h2osfc[c], LV(t_soisno, 20), &S->t_h2osfc_bef[c], LV(tssbef, 20));
+    elmo_ct_ground_temp(&S->land, S->snl[c], S->frac_sno_eff[c], S->frac_h2osfc[c], S->t_h2osfc[c], LV(t_soisno, 20),
+                        &S->t_grnd[c]);
+    elmo_ct_calc_soilalpha(&S->land, S->frac_sno[c], S->frac_h2osfc[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20),
+                           LV(dz, 20), LV(t_soisno, 20), LV(watsat, 15), LV(sucsat, 15), LV(bsw, 15), LV(watdry, 15),
+                           LV(watopt, 15), &qred, &hr, &soilalpha);
+    elmo_ct_calc_soilbeta(&S->land, S->frac_sno[c], S->frac_h2osfc[c], LV(watsat, 15), LV(watfc, 15),
+                          LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(dz, 20), &S->soilbeta[c]);
+    elmo_ct_humidities(&S->land, S->snl[c], S->forc_qbot[c], S->forc_pbot[c], S->t_h2osfc[c], S->t_grnd[c],
+                       S->frac_sno[c], S->frac_sno_eff[c], S->frac_h2osfc[c], qred, hr, LV(t_soisno, 20),
+                       &S->qg_snow[c], &S->qg_soil[c], &S->qg[c], &S->qg_h2osfc[c], &S->dqgdT[c]);
+    elmo_ct_ground_properties(&S->land, S->snl[c], S->frac_sno[c], S->forc_thbot[c], S->forc_qbot[c], S->elai[c],
+                              S->esai[c], S->htop[c], S->displar, S->z0mr, LV(h2osoi_liq, 20), LV(h2osoi_ice, 20),
+                              &S->emg[c], &S->emv[c], &S->htvp[c], &S->z0mg[c], &S->z0hg[c], &S->z0qg[c], &S->z0mv[c],
+                              &S->z0hv[c], &S->z0qv[c], &S->thv[c], &S->z0m[c], &S->displa[c]);
+    elmo_ct_forcing_height(&S->land, S->veg_active[c], S->frac_veg_nosno[c], S->z0m[c], S->z0mg[c], S->forc_tbot[c],
+                           S->displa[c], &S->forc_hgt_u_patch[c], &S->forc_hgt_t_patch[c], &S->forc_hgt_q_patch[c],
+                           &S->thm[c]);
+    elmo_ct_init_energy_fluxes(&S->land, &S->eflx_sh_tot[c], &S->eflx_lh_tot[c], &S->eflx_sh_veg[c],
+                               &S->qflx_evap_tot[c], &S->qflx_evap_veg[c], &S->qflx_tran_veg[c]);
+  }
+}
+
+/* bareground_fluxes_kokkos.cc:7-123 */
+void elmo_bareground_fluxes(elmo_state *S) { elmo_bareground_fluxes_given(S, NULL); }
+
+/* rho_in (optional): forc_rho per column from the fixture, as test/test_BGFlux.cc:226 passes it */
+void elmo_bareground_fluxes_given(elmo_state *S, const double *rho_in)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double zldis = 0.0, displa = 0.0, dth = 0.0, dqh = 0.0, obu = 0.0, ur = 0.0, um = 0.0, temp1 = 0.0, temp2 = 0.0,
+           temp12m = 0.0, temp22m = 0.0, ustar = 0.0;
+    double forc_rho = rho_in ? rho_in[c] : elmo_derive_forc_rho(S->forc_pbot[c], S->forc_qbot[c], S->forc_tbot[c]);
+    elmo_bg_initialize_flux(&S->land, S->frac_veg_nosno[c], S->forc_u[c], S->forc_v[c], S->forc_qbot[c],
+                            S->forc_thbot[c], S->forc_hgt_u_patch[c], S->thm[c], S->thv[c], S->t_grnd[c], S->qg[c],
+                            S->z0mg[c], &S->dlrad[c], &S->ulrad[c], &zldis, &displa, &dth, &dqh, &obu, &ur, &um);
+    elmo_bg_stability_iteration(&S->land, S->frac_veg_nosno[c], S->forc_hgt_t_patch[c], S->forc_hgt_u_patch[c],
+                                S->forc_hgt_q_patch[c], S->z0mg[c], zldis, displa, dth, dqh, ur, S->forc_qbot[c],
+                                S->forc_thbot[c], S->thv[c], &S->z0hg[c], &S->z0qg[c], &obu, &um, &temp1, &temp2,
+                                &temp12m, &temp22m, &ustar);
+    elmo_bg_compute_flux(&S->land, S->frac_veg_nosno[c], S->snl[c], forc_rho, S->soilbeta[c], S->dqgdT[c], S->htvp[c],
+                         S->t_h2osfc[c], S->qg_snow[c], S->qg_soil[c], S->qg_h2osfc[c], LV(t_soisno, 20),
+                         S->forc_pbot[c], dth, dqh, temp1, temp2, temp12m, temp22m, ustar, S->forc_qbot[c], S->thm[c],
+                         &S->cgrnds[c], &S->cgrndl[c], &S->cgrnd[c], &S->eflx_sh_grnd[c], &S->eflx_sh_tot[c],
+                         &S->eflx_sh_snow[c], &S->eflx_sh_soil[c], &S->eflx_sh_h2osfc[c], &S->qflx_evap_soi[c],
+                         &S->qflx_evap_tot[c], &S->qflx_ev_snow[c], &S->qflx_ev_soil[c], &S->qflx_ev_h2osfc[c],
+                         &S->t_ref2m[c], &S->q_ref2m[c], &S->rh_ref2m[c]);
+  }
+}
+
+/* canopy_fluxes_kokkos.cc:6-265.  psn_pft(idx) of the reference is the PFT parameter struct of column
+ * idx; here it is looked up in the shared table by vtype[idx]. */
+void elmo_canopy_fluxes(elmo_state *S, double dt) { elmo_canopy_fluxes_given(S, dt, NULL, NULL, NULL, NULL); }
+
+/* Same three L2 calls, but - when the arrays are non-NULL - with forc_rho / forc_po2 / forc_pco2 handed in
+ * per column the way test/test_CanFlux.cc:421-449 feeds them from the fixture instead of deriving them.
+ * niter (optional) receives the leaf-temperature iteration count of each column. */
+void elmo_canopy_fluxes_given(elmo_state *S, double dt, const double *rho_in, const double *po2_in,
+                              const double *pco2_in, int *niter)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    elmo_cf_scratch w;
+    memset(&w, 0, sizeof(w));
+    const elmo_pft_psn *psn = &S->pft_psn[S->vtype[c]];
+    double forc_po2 = po2_in ? po2_in[c] : elmo_derive_forc_po2(S->forc_pbot[c]);
+    double forc_pco2 = pco2_in ? pco2_in[c] : elmo_derive_forc_pco2(S->forc_pbot[c]);
+    double forc_rho = rho_in ? rho_in[c] : elmo_derive_forc_rho(S->forc_pbot[c], S->forc_qbot[c], S->forc_tbot[c]);
+    unsigned err = 0;
+    err |= elmo_cf_initialize_flux(&S->land, S->snl[c], S->frac_veg_nosno[c], S->frac_sno[c], S->forc_hgt_u_patch[c],
+                                   S->thm[c], S->thv[c], S->max_dayl, S->dayl, S->altmax_indx[c],
+                                   S->altmax_lastyear_indx[c], LV(t_soisno, 20), LV(h2osoi_ice, 20), LV(h2osoi_liq, 20),
+                                   LV(dz, 20), LV(rootfr, 15), psn->tc_stress, LV(sucsat, 15), LV(watsat, 15),
+                                   LV(bsw, 15), psn->smpso, psn->smpsc, S->elai[c], S->esai[c], S->emv[c], S->emg[c],
+                                   S->qg[c], S->t_grnd[c], S->forc_tbot[c], S->forc_pbot[c], S->forc_lwrad[c],
+                                   S->forc_u[c], S->forc_v[c], S->forc_qbot[c], S->forc_thbot[c], S->z0mg[c],
+                                   &S->btran[c], &S->displa[c], &S->z0mv[c], &S->z0hv[c], &S->z0qv[c], LV(rootr, 15),
+                                   LV(eff_porosity, 15), &w, &S->t_veg[c]);
+    err |= elmo_cf_stability_iteration(
+        &S->land, dt, S->snl[c], S->frac_veg_nosno[c], S->frac_sno[c], S->forc_hgt_u_patch[c], S->forc_hgt_t_patch[c],
+        S->forc_hgt_q_patch[c], S->fwet[c], S->fdry[c], S->laisun[c], S->laisha[c], forc_rho, S->snow_depth[c],
+        S->soilbeta[c], S->frac_h2osfc[c], S->t_h2osfc[c], S->sabv[c], S->h2ocan[c], S->htop[c], LV(t_soisno, 20),
+        S->displa[c], S->elai[c], S->esai[c], S->t_grnd[c], S->forc_pbot[c], S->forc_qbot[c], S->forc_thbot[c],
+        S->z0mg[c], S->z0mv[c], S->z0hv[c], S->z0qv[c], S->thm[c], S->thv[c], S->qg[c], psn, S->nrad[c], S->t10[c],
+        LV(tlai_z, 1), S->vcmaxcintsha[c], S->vcmaxcintsun[c], LV(parsha_z, 1), LV(parsun_z, 1), LV(laisha_z, 1),
+        LV(laisun_z, 1), forc_pco2, forc_po2, &S->btran[c], &S->qflx_tran_veg[c], &S->qflx_evap_veg[c],
+        &S->eflx_sh_veg[c], &w, &S->t_veg[c], niter ? &niter[c] : NULL);
+    elmo_cf_compute_flux(&S->land, dt, S->snl[c], S->frac_veg_nosno[c], S->frac_sno[c], LV(t_soisno, 20),
+                         S->frac_h2osfc[c], S->t_h2osfc[c], S->sabv[c], S->qg_snow[c], S->qg_soil[c], S->qg_h2osfc[c],
+                         S->dqgdT[c], S->htvp[c], &w, S->t_veg[c], S->t_grnd[c], S->forc_pbot[c], S->qflx_tran_veg[c],
+                         S->qflx_evap_veg[c], S->eflx_sh_veg[c], S->forc_qbot[c], forc_rho, S->thm[c], S->emv[c],
+                         S->emg[c], S->forc_lwrad[c], &S->h2ocan[c], &S->eflx_sh_grnd[c], &S->eflx_sh_snow[c],
+                         &S->eflx_sh_soil[c], &S->eflx_sh_h2osfc[c], &S->qflx_evap_soi[c], &S->qflx_ev_snow[c],
+                         &S->qflx_ev_soil[c], &S->qflx_ev_h2osfc[c], &S->dlrad[c], &S->ulrad[c], &S->cgrnds[c],
+                         &S->cgrndl[c], &S->cgrnd[c], &S->t_ref2m[c], &S->q_ref2m[c], &S->rh_ref2m[c]);
+    S->err_flags[c] |= err;
+  }
+}
+
+/* albedo_kokkos.cc:10-376 */
+void elmo_albedo_snicar(elmo_state *S) { elmo_albedo_snicar_ex(S, NULL, NULL); }
+
+/* fabd_sun_out / fabd_sha_out (optional, [ncols][2]): the wrapper-local fabd_sun / fabd_sha, which the
+ * reference computes but never stores in the state; test/test_SurfAlb.cc compares them. */
+void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha_out)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    /* wrapper-local, zero-filled Views (:19-38) */
+    int snw_rds_lcl[5] = {0};
+    double h2osoi_ice_lcl[5] = {0}, h2osoi_liq_lcl[5] = {0}, albout_lcl[5] = {0}, flx_slrd_lcl[5] = {0},
+           flx_slri_lcl[5] = {0}, tsai_z[1] = {0}, fabd_sun[2] = {0}, fabd_sha[2] = {0};
+    double flx_abs_lcl[6 * 5] = {0}, mss_cnc_aer_in_fdb[5 * 8] = {0}, g_star[5 * 5] = {0}, omega_star[5 * 5] = {0},
+           tau_star[5 * 5] = {0}, flx_absd_snw[6 * 2] = {0}, flx_absi_snw[6 * 2] = {0};
+    int snl_top = 0, snl_btm = 0, flg_nosnl = 0;
+    double mu_not = 0.0;
+    unsigned err = 0;
+    const elmo_pft_alb *alb_pft = &S->pft_alb[S->vtype[c]];
+    const int urbpoi = S->land.urbpoi;
+
+    elmo_sa_init_timestep(urbpoi, S->elai[c], LV(cnc_bcphi, 5), LV(cnc_bcpho, 5), LV(cnc_dst1, 5), LV(cnc_dst2, 5),
+                          LV(cnc_dst3, 5), LV(cnc_dst4, 5), &S->vcmaxcintsun[c], &S->vcmaxcintsha[c], LV(albsod, 2),
+                          LV(albsoi, 2), LV(albgrd, 2), LV(albgri, 2), LV(albd, 2), LV(albi, 2), LV(fabd, 2), fabd_sun,
+                          fabd_sha, LV(fabi, 2), LV(fabi_sun, 2), LV(fabi_sha, 2), LV(ftdd, 2), LV(ftid, 2),
+                          LV(ftii, 2), LV(flx_absdv, 6), LV(flx_absdn, 6), LV(flx_absiv, 6), LV(flx_absin, 6),
+                          mss_cnc_aer_in_fdb);
+    elmo_sa_soil_albedo(&S->land, S->snl[c], S->t_grnd[c], S->coszen[c], LV(h2osoi_vol, 15), S->albsat[S->isoicol[c]],
+                        S->albdry[S->isoicol[c]], LV(albsod, 2), LV(albsoi, 2));
+    for (int flg_slr_in = 1; flg_slr_in <= 2; flg_slr_in++) {
+      double *flx_abs = (flg_slr_in == 1) ? flx_absd_snw : flx_absi_snw;
+      double *albout = (flg_slr_in == 1) ? LV(albsnd, 2) : LV(albsni, 2);
+      err |= elmo_sn_init_timestep(urbpoi, flg_slr_in, S->coszen[c], S->h2osno[c], S->snl[c], LV(h2osoi_liq, 20),
+                                   LV(h2osoi_ice, 20), LV(snw_rds, 5), &snl_top, &snl_btm, flx_abs_lcl, flx_abs,
+                                   &flg_nosnl, h2osoi_ice_lcl, h2osoi_liq_lcl, snw_rds_lcl, &mu_not, flx_slrd_lcl,
+                                   flx_slri_lcl);
+      elmo_sn_snow_aerosol_mie_params(urbpoi, flg_slr_in, snl_top, snl_btm, S->coszen[c], S->h2osno[c], snw_rds_lcl,
+                                      h2osoi_ice_lcl, h2osoi_liq_lcl, &S->snicar, mss_cnc_aer_in_fdb, g_star,
+                                      omega_star, tau_star);
+      err |= elmo_sn_snow_radiative_transfer_solver(urbpoi, flg_slr_in, flg_nosnl, snl_top, snl_btm, S->coszen[c],
+                                                    S->h2osno[c], mu_not, flx_slrd_lcl, flx_slri_lcl, LV(albsoi, 2),
+                                                    g_star, omega_star, tau_star, albout_lcl, flx_abs_lcl);
+      elmo_sn_snow_albedo_radiation_factor(urbpoi, flg_slr_in, snl_top, S->coszen[c], mu_not, S->h2osno[c],
+                                           snw_rds_lcl, LV(albsoi, 2), albout_lcl, flx_abs_lcl, albout, flx_abs);
+    }
+    elmo_sa_ground_albedo(urbpoi, S->coszen[c], S->frac_sno[c], LV(albsod, 2), LV(albsoi, 2), LV(albsnd, 2),
+                          LV(albsni, 2), LV(albgrd, 2), LV(albgri, 2));
+    elmo_sa_flux_absorption_factor(&S->land, S->coszen[c], S->frac_sno[c], LV(albsod, 2), LV(albsoi, 2), LV(albsnd, 2),
+                                   LV(albsni, 2), flx_absd_snw, flx_absi_snw, LV(flx_absdv, 6), LV(flx_absdn, 6),
+                                   LV(flx_absiv, 6), LV(flx_absin, 6));
+    err |= elmo_sa_canopy_layer_lai(urbpoi, S->elai[c], S->esai[c], S->tlai[c], S->tsai[c], &S->nrad[c], LV(tlai_z, 1),
+                                    tsai_z, LV(fsun_z, 1), LV(fabd_sun_z, 1), LV(fabd_sha_z, 1), LV(fabi_sun_z, 1),
+                                    LV(fabi_sha_z, 1));
+    elmo_sa_two_stream_solver(&S->land, S->nrad[c], S->coszen[c], S->t_veg[c], S->fwet[c], S->elai[c], S->esai[c],
+                              LV(tlai_z, 1), tsai_z, LV(albgrd, 2), LV(albgri, 2), alb_pft, &S->vcmaxcintsun[c],
+                              &S->vcmaxcintsha[c], LV(albd, 2), LV(ftid, 2), LV(ftdd, 2), LV(fabd, 2), fabd_sun,
+                              fabd_sha, LV(albi, 2), LV(ftii, 2), LV(fabi, 2), LV(fabi_sun, 2), LV(fabi_sha, 2),
+                              LV(fsun_z, 1), LV(fabd_sun_z, 1), LV(fabd_sha_z, 1), LV(fabi_sun_z, 1),
+                              LV(fabi_sha_z, 1));
+    if (fabd_sun_out) {
+      fabd_sun_out[c * 2] = fabd_sun[0];
+      fabd_sun_out[c * 2 + 1] = fabd_sun[1];
+    }
+    if (fabd_sha_out) {
+      fabd_sha_out[c * 2] = fabd_sha[0];
+      fabd_sha_out[c * 2 + 1] = fabd_sha[1];
+    }
+    S->err_flags[c] |= err;
+  }
+}
+
+/* elm_kokkos_interface.cc:289-307 */
+void elmo_timestep7(elmo_state *S, double dt)
+{
+  elmo_frac_wet(S);
+  elmo_albedo_snicar(S);
+  elmo_canopy_hydrology(S, dt);
+  elmo_surface_radiation(S);
+  elmo_canopy_temperature(S);
+  elmo_bareground_fluxes(S);
+  elmo_canopy_fluxes(S, dt);
+}

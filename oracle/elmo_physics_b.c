@@ -1,0 +1,788 @@
+/*
+ * elmo_physics_b.c - oracle restatement, part B: soil moisture stress, photosynthesis, canopy fluxes.
+ * TEST INFRASTRUCTURE - see elm_oracle.h.  References are paths under /root/reference.
+ */
+#include "elm_oracle.h"
+#include "elmo_const.h"
+
+#include <math.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * src/physics/soil_moist_stress_impl.hh
+ * ---------------------------------------------------------------------------------------------- */
+
+/* :62-73 */
+void elmo_sms_calc_effective_soilporosity(const double *watsat, const double *h2osoi_ice, const double *dz,
+                                          double *eff_por)
+{
+  for (int i = 0; i < ELMO_NLEVGRND; i++) {
+    double vol_ice = dmin(watsat[i], (h2osoi_ice[ELMO_NLEVSNO + i] / (DENICE * dz[ELMO_NLEVSNO + i])));
+    eff_por[i] = watsat[i] - vol_ice;
+  }
+}
+
+/* :77-86 */
+void elmo_sms_calc_volumetric_h2oliq(const double *eff_por, const double *h2osoi_liq, const double *dz,
+                                     double *vol_liq)
+{
+  for (int i = 0; i < ELMO_NLEVGRND; i++) {
+    vol_liq[ELMO_NLEVSNO + i] = dmin(eff_por[i], (h2osoi_liq[ELMO_NLEVSNO + i] / (dz[ELMO_NLEVSNO + i] * DENH2O)));
+  }
+}
+
+/* :89-133 (perchroot == perchroot_alt == 0, elm_constants.h:14-15, so rootfr_unf is never used) */
+void elmo_sms_calc_root_moist_stress(const double *h2osoi_liqvol, const double *rootfr, const double *t_soisno,
+                                     double tc_stress, const double *sucsat, const double *watsat, const double *bsw,
+                                     double smpso, double smpsc, const double *eff_porosity, int altmax_indx,
+                                     int altmax_lastyear_indx, double *rootr, double *btran)
+{
+  const double btran0 = 0.0;
+  (void)altmax_indx;
+  (void)altmax_lastyear_indx;
+  for (int i = 0; i < ELMO_NLEVGRND; i++) {
+    if (h2osoi_liqvol[ELMO_NLEVSNO + i] <= 0.0 || t_soisno[ELMO_NLEVSNO + i] <= TFRZ + tc_stress) {
+      rootr[i] = 0.0;
+    } else {
+      const double s_node = dmax(h2osoi_liqvol[ELMO_NLEVSNO + i] / eff_porosity[i], 0.01);
+      double smp_node = -sucsat[i] * pow(s_node, (-bsw[i])); /* soil_suction :21 */
+      smp_node = dmax(smpsc, smp_node);
+      double rresis = dmin((eff_porosity[i] / watsat[i]) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
+      rootr[i] = rootfr[i] * rresis;
+      *btran += dmax(rootr[i], 0.0);
+    }
+  }
+  for (int i = 0; i < ELMO_NLEVGRND; i++) {
+    if (*btran > btran0) {
+      rootr[i] /= *btran;
+    } else {
+      rootr[i] = 0.0;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * src/physics/photosynthesis_impl.hh
+ * ---------------------------------------------------------------------------------------------- */
+
+/* :623-635 */
+static double psn_ft(double tl, double ha) { return exp(ha / (RGAS * 1.0e-3 * (TFRZ + 25.0)) * (1.0 - (TFRZ + 25.0) / tl)); }
+static double psn_fth(double tl, double hd, double se, double scaleFactor)
+{
+  return scaleFactor / (1.0 + exp((-hd + se * tl) / (RGAS * 1.0e-3 * tl)));
+}
+static double psn_fth25(double hd, double se)
+{
+  return 1.0 + exp((-hd + se * (TFRZ + 25.0)) / (RGAS * 1.0e-3 * (TFRZ + 25.0)));
+}
+
+/* :286-302 quadratic; flags where the reference throws */
+static unsigned psn_quadratic(double a, double b, double c, double *r1, double *r2)
+{
+  unsigned err = 0;
+  double q;
+  if (a == 0.0) err |= ELMO_ERR_PSN_QUADRATIC;
+  if (b >= 0.0) {
+    q = -0.5 * (b + sqrt(b * b - 4.0 * a * c));
+  } else {
+    q = -0.5 * (b - sqrt(b * b - 4.0 * a * c));
+  }
+  *r1 = q / a;
+  if (q != 0.0) {
+    *r2 = c / q;
+  } else {
+    *r2 = 1.0e36;
+  }
+  return err;
+}
+
+/* everything ci_func/brent/hybrid pass around by reference in the reference code */
+typedef struct {
+  /* constant inputs */
+  double gb_mol, je, cair, oair, lmr_z, par_z, rh_can, vcmax_z, forc_pbot, cp, kc, ko, qe, tpu_z, kp_z, theta_cj, bbb,
+      mbb;
+  int c3flag;
+  /* in/out */
+  double gs_mol, ac, aj, ap, ag, an;
+  unsigned err;
+} psn_ctx;
+
+/* :308-390 ci_func */
+static void psn_ci_func(double ci, double *fval, psn_ctx *k)
+{
+  const double theta_ip = 0.95;
+  if (k->c3flag) {
+    k->ac = k->vcmax_z * dmax(ci - k->cp, 0.0) / (ci + k->kc * (1.0 + k->oair / k->ko));
+    k->aj = k->je * dmax(ci - k->cp, 0.0) / (4.0 * ci + 8.0 * k->cp);
+    k->ap = 3.0 * k->tpu_z;
+  } else {
+    k->ac = k->vcmax_z;
+    k->aj = k->qe * k->par_z * 4.6;
+    k->ap = k->kp_z * dmax(ci, 0.0) / k->forc_pbot;
+  }
+  double aquad = k->theta_cj;
+  double bquad = -(k->ac + k->aj);
+  double cquad = k->ac * k->aj;
+  double r1, r2;
+  k->err |= psn_quadratic(aquad, bquad, cquad, &r1, &r2);
+  double ai = dmin(r1, r2);
+
+  aquad = theta_ip;
+  bquad = -(ai + k->ap);
+  cquad = ai * k->ap;
+  k->err |= psn_quadratic(aquad, bquad, cquad, &r1, &r2);
+  k->ag = dmin(r1, r2);
+
+  k->an = k->ag - k->lmr_z;
+  if (k->an < 0.0) {
+    *fval = 0.0;
+    return;
+  }
+  double cs = k->cair - 1.4 / k->gb_mol * k->an * k->forc_pbot;
+  cs = dmax(cs, 1.e-6);
+  aquad = cs;
+  bquad = cs * (k->gb_mol - k->bbb) - k->mbb * k->an * k->forc_pbot;
+  cquad = -k->gb_mol * (cs * k->bbb + k->mbb * k->an * k->forc_pbot * k->rh_can);
+  k->err |= psn_quadratic(aquad, bquad, cquad, &r1, &r2);
+  k->gs_mol = dmax(r1, r2);
+  *fval = ci - k->cair + k->an * k->forc_pbot * (1.4 * k->gs_mol + 1.6 * k->gb_mol) / (k->gb_mol * k->gs_mol);
+}
+
+/* :396-511 brent */
+static void psn_brent(double *x, double x1, double x2, double f1, double f2, double tol, psn_ctx *k)
+{
+  const int ITMAX = 20;
+  const double EPS = 1.0e-2;
+  double d = 0.0, e = 0.0, p, q, r, s, tol1, xm;
+  double a = x1;
+  double b = x2;
+  double fa = f1;
+  double fb = f2;
+  if ((fa > 0.0 && fb > 0.0) || (fa < 0.0 && fb < 0.0)) {
+    k->err |= ELMO_ERR_PSN_BRENT_BRACKET;
+  }
+  double c = b;
+  double fc = fb;
+  int iter = 0;
+  while (iter != ITMAX) {
+    iter += 1;
+    if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) {
+      c = a;
+      fc = fa;
+      d = b - a;
+      e = d;
+    }
+    if (fabs(fc) < fabs(fb)) {
+      a = b;
+      b = c;
+      c = a;
+      fa = fb;
+      fb = fc;
+      fc = fa;
+    }
+    tol1 = 2.0 * EPS * fabs(b) + 0.5 * tol;
+    xm = 0.5 * (c - b);
+    if (fabs(xm) <= tol1 || fb == 0.0) {
+      *x = b;
+      return;
+    }
+    if (fabs(e) >= tol1 && fabs(fa) > fabs(fb)) {
+      s = fb / fa;
+      if (a == c) {
+        p = 2.0 * xm * s;
+        q = 1.0 - s;
+      } else {
+        q = fa / fc;
+        r = fb / fc;
+        p = s * (2.0 * xm * q * (q - r) - (b - a) * (r - 1.0));
+        q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) {
+        q *= -1.0;
+      }
+      p = fabs(p);
+      if (2.0 * p < dmin(3.0 * xm * q - fabs(tol1 * q), fabs(e * q))) {
+        e = d;
+        d = p / q;
+      } else {
+        d = xm;
+        e = d;
+      }
+    } else {
+      d = xm;
+      e = d;
+    }
+    a = b;
+    fa = fb;
+    if (fabs(d) > tol1) {
+      b = b + d;
+    } else {
+      b = b + copysign(tol1, xm);
+    }
+    psn_ci_func(b, &fb, k);
+    if (fb == 0.0) {
+      break;
+    }
+  }
+  *x = b;
+}
+
+/* :517-620 hybrid */
+static void psn_hybrid(double *x0, psn_ctx *k)
+{
+  const double eps = 1.0e-2;
+  const double eps1 = 1.0e-4;
+  const int itmax = 40;
+  double x1, f0, f1, x, dx, tol, minx, minf;
+
+  psn_ci_func(*x0, &f0, k);
+  if (f0 == 0.0) return;
+  minx = *x0;
+  minf = f0;
+  x1 = *x0 * 0.99;
+  psn_ci_func(x1, &f1, k);
+  if (f1 == 0.0) {
+    *x0 = x1;
+    return;
+  }
+  if (f1 < minf) {
+    minx = x1;
+    minf = f1;
+  }
+  int iter = 0;
+  for (;;) {
+    iter += 1;
+    dx = -f1 * (x1 - *x0) / (f1 - f0);
+    x = x1 + dx;
+    tol = fabs(x) * eps;
+    if (fabs(dx) < tol) {
+      *x0 = x;
+      break;
+    }
+    *x0 = x1;
+    f0 = f1;
+    x1 = x;
+    psn_ci_func(x1, &f1, k);
+    if (f1 < minf) {
+      minx = x1;
+      minf = f1;
+    }
+    if (fabs(f1) <= eps1) {
+      *x0 = x1;
+      break;
+    }
+    if (f1 * f0 < 0.0) {
+      psn_brent(&x, *x0, x1, f0, f1, tol, k);
+      *x0 = x;
+      break;
+    }
+    if (iter > itmax) {
+      psn_ci_func(minx, &f1, k);
+      break;
+    }
+  }
+}
+
+/* :9-282 photosynthesis (nlevcan == 1, so nscaler = vcmaxcint) */
+unsigned elmo_psn_photosynthesis(const elmo_pft_psn *psnveg, int nrad, double forc_pbot, double t_veg, double t10,
+                                 double esat_tv, double eair, double oair, double cair, double rb, double btran,
+                                 double dayl_factor, double thm, const double *tlai_z, double vcmaxcint,
+                                 const double *par_z, const double *lai_z, double *ci_z, double *rs)
+{
+  const double fnps = 0.15;
+  const double theta_psii = 0.7;
+  const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
+  unsigned err = 0;
+  int c3flag = 0;
+  if (round(psnveg->c3psn) == 1) {
+    c3flag = 1;
+  } else if (round(psnveg->c3psn) == 0) {
+    c3flag = 0;
+  }
+  double lnc = 1.0 / (psnveg->slatop * psnveg->leafcn);
+  double act25 = psnveg->act25 * 1000.0 / 60.0;
+  double vcmax25top = lnc * psnveg->flnr * psnveg->fnr * act25 * dayl_factor;
+  vcmax25top *= psnveg->fnitr;
+  double jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
+  double tpu25top = 0.167 * vcmax25top;
+  double kp25top = 20000.0 * vcmax25top;
+  double kn;
+  if (dayl_factor == 0.0) {
+    kn = 0.0;
+  } else {
+    kn = exp(0.00963 * vcmax25top / dayl_factor - 2.43);
+  }
+  (void)kn;
+  double lmr25top;
+  if (c3flag) {
+    lmr25top = vcmax25top * 0.015;
+  } else {
+    lmr25top = vcmax25top * 0.025;
+  }
+
+  double laican = 0.0;
+  double lmr_z[ELMO_NLEVCAN], vcmax_z[ELMO_NLEVCAN], tpu_z[ELMO_NLEVCAN], kp_z[ELMO_NLEVCAN], jmax_z[ELMO_NLEVCAN];
+  for (int iv = 0; iv < nrad; iv++) {
+    if (iv == 0) {
+      laican = 0.5 * tlai_z[iv];
+    } else {
+      laican += 0.5 * (tlai_z[iv - 1] + tlai_z[iv]);
+    }
+    double nscaler = vcmaxcint;
+    double lmr25 = lmr25top * nscaler;
+    if (c3flag) {
+      double lmrc = psn_fth25(psnveg->lmrhd, psnveg->lmrse);
+      lmr_z[iv] = lmr25 * psn_ft(t_veg, psnveg->lmrha) * psn_fth(t_veg, psnveg->lmrhd, psnveg->lmrse, lmrc);
+    } else {
+      lmr_z[iv] = lmr25 * pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+      lmr_z[iv] /= (1.0 + exp(1.3 * (t_veg - (TFRZ + 55.0))));
+    }
+    if (par_z[iv] <= 0.0) {
+      vcmax_z[iv] = 0.0;
+      jmax_z[iv] = 0.0;
+      tpu_z[iv] = 0.0;
+      kp_z[iv] = 0.0;
+    } else {
+      double vcmax25 = vcmax25top * nscaler;
+      double jmax25 = jmax25top * nscaler;
+      double tpu25 = tpu25top * nscaler;
+      double kp25 = kp25top * nscaler;
+      double vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+      double jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+      double tpuse = vcmaxse;
+      double vcmaxc = psn_fth25(psnveg->vcmaxhd, vcmaxse);
+      double jmaxc = psn_fth25(psnveg->jmaxhd, jmaxse);
+      double tpuc = psn_fth25(psnveg->tpuhd, tpuse);
+      vcmax_z[iv] = vcmax25 * psn_ft(t_veg, psnveg->vcmaxha) * psn_fth(t_veg, psnveg->vcmaxhd, vcmaxse, vcmaxc);
+      jmax_z[iv] = jmax25 * psn_ft(t_veg, psnveg->jmaxha) * psn_fth(t_veg, psnveg->jmaxhd, jmaxse, jmaxc);
+      tpu_z[iv] = tpu25 * psn_ft(t_veg, psnveg->tpuha) * psn_fth(t_veg, psnveg->tpuhd, tpuse, tpuc);
+      if (!c3flag) {
+        vcmax_z[iv] = vcmax25 * pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+        vcmax_z[iv] /= (1.0 + exp(0.2 * ((TFRZ + 15.0) - t_veg)));
+        vcmax_z[iv] /= (1.0 + exp(0.3 * (t_veg - (TFRZ + 40.0))));
+      }
+      kp_z[iv] = kp25 * pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+    }
+    vcmax_z[iv] *= btran;
+    lmr_z[iv] *= btran;
+  }
+
+  double cf = forc_pbot / (RGAS * 1.0e-3 * thm) * 1.e06;
+  double gb = 1.0 / rb;
+  double gb_mol = gb * cf;
+  double rs_z[ELMO_NLEVCAN];
+  double gs_mol[ELMO_NLEVCAN];
+  double bbb = dmax(psnveg->bbbopt * btran, 1.0);
+  double rsmax0 = 2.0e4;
+  double kc25 = (404.9 / 1.e06) * forc_pbot;
+  double ko25 = (278.4 / 1.e03) * forc_pbot;
+  double cp25 = 0.5 * oair / sco;
+  double kc = kc25 * psn_ft(t_veg, psnveg->kcha);
+  double ko = ko25 * psn_ft(t_veg, psnveg->koha);
+  double cp = cp25 * psn_ft(t_veg, psnveg->cpha);
+
+  for (int iv = 0; iv < nrad; iv++) {
+    if (par_z[iv] <= 0.0) {
+      ci_z[iv] = 0.0;
+      rs_z[iv] = dmin(rsmax0, 1.0 / bbb * cf);
+    } else {
+      double ceair = dmin(eair, esat_tv);
+      double rh_can = ceair / esat_tv;
+      double qabs = 0.5 * (1.0 - fnps) * par_z[iv] * 4.6;
+      double aquad = theta_psii;
+      double bquad = -(qabs + jmax_z[iv]);
+      double cquad = qabs * jmax_z[iv];
+      double r1, r2;
+      err |= psn_quadratic(aquad, bquad, cquad, &r1, &r2);
+      double je = dmin(r1, r2);
+      if (c3flag) {
+        ci_z[iv] = 0.7 * cair;
+      } else {
+        ci_z[iv] = 0.4 * cair;
+      }
+      double ciold = ci_z[iv];
+
+      psn_ctx k;
+      k.gb_mol = gb_mol;
+      k.je = je;
+      k.cair = cair;
+      k.oair = oair;
+      k.lmr_z = lmr_z[iv];
+      k.par_z = par_z[iv];
+      k.rh_can = rh_can;
+      k.vcmax_z = vcmax_z[iv];
+      k.forc_pbot = forc_pbot;
+      k.c3flag = c3flag;
+      k.cp = cp;
+      k.kc = kc;
+      k.ko = ko;
+      k.qe = psnveg->qe;
+      k.tpu_z = tpu_z[iv];
+      k.kp_z = kp_z[iv];
+      k.theta_cj = psnveg->theta_cj;
+      k.bbb = bbb;
+      k.mbb = psnveg->mbbopt;
+      k.gs_mol = 0.0; /* uninitialised in the reference; only read after being set or replaced by bbb */
+      k.ac = k.aj = k.ap = k.ag = k.an = 0.0;
+      k.err = 0;
+      psn_hybrid(&ciold, &k);
+      err |= k.err;
+      gs_mol[iv] = k.gs_mol;
+      double an = k.an;
+      if (an < 0.0) {
+        gs_mol[iv] = bbb;
+      }
+      double cs = cair - 1.4 / gb_mol * an * forc_pbot;
+      cs = dmax(cs, 1.0e-6);
+      ci_z[iv] = cair - an * forc_pbot * (1.4 * gs_mol[iv] + 1.6 * gb_mol) / (gb_mol * gs_mol[iv]);
+      double gs = gs_mol[iv] / cf;
+      rs_z[iv] = dmin(1.0 / gs, rsmax0);
+      if (gs_mol[iv] < 0.0) {
+        err |= ELMO_ERR_PSN_NEG_GS;
+      }
+      double hs = (gb_mol * ceair + gs_mol[iv] * esat_tv) / ((gb_mol + gs_mol[iv]) * esat_tv);
+      double gs_mol_err = psnveg->mbbopt * dmax(an, 0.0) * hs / cs * forc_pbot + bbb;
+      if (fabs(gs_mol[iv] - gs_mol_err) > 1.0e-01) {
+        err |= ELMO_WARN_PSN_BALL_BERRY;
+      }
+    }
+  }
+
+  laican = 0.0;
+  double gscan = 0.0;
+  for (int iv = 0; iv < nrad; iv++) {
+    gscan += lai_z[iv] / (rb + rs_z[iv]);
+    laican += lai_z[iv];
+  }
+  if (laican > 0.0) {
+    *rs = laican / gscan - rb;
+  } else {
+    *rs = 0.0;
+  }
+  return err;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * src/physics/canopy_fluxes_impl.hh
+ * ---------------------------------------------------------------------------------------------- */
+
+/* :95-184 initialize_flux */
+unsigned elmo_cf_initialize_flux(const elmo_land *L, int snl, int frac_veg_nosno, double frac_sno,
+                                 double forc_hgt_u_patch, double thm, double thv, double max_dayl, double dayl,
+                                 int altmax_indx, int altmax_lastyear_indx, const double *t_soisno,
+                                 const double *h2osoi_ice, const double *h2osoi_liq, const double *dz,
+                                 const double *rootfr, double tc_stress, const double *sucsat, const double *watsat,
+                                 const double *bsw, double smpso, double smpsc, double elai, double esai, double emv,
+                                 double emg, double qg, double t_grnd, double forc_t, double forc_pbot,
+                                 double forc_lwrad, double forc_u, double forc_v, double forc_q, double forc_th,
+                                 double z0mg, double *btran, double *displa, double *z0mv, double *z0hv, double *z0qv,
+                                 double *rootr, double *eff_porosity, elmo_cf_scratch *w, double *t_veg)
+{
+  const double tlsai_crit = 2.0;
+  const double btran0 = 0.0;
+  unsigned err = 0;
+  (void)snl;
+  (void)frac_sno;
+  if (!L->lakpoi && !L->urbpoi) {
+    if (frac_veg_nosno == 0) {
+      *btran = 0.0;
+      *t_veg = forc_t;
+      for (int i = 0; i < ELMO_NLEVGRND; i++) rootr[i] = 0.0;
+    } else {
+      *btran = btran0;
+      w->dayl_factor = dmin(1.0, dmax(0.01, (dayl * dayl) / (max_dayl * max_dayl)));
+      elmo_sms_calc_effective_soilporosity(watsat, h2osoi_ice, dz, eff_porosity);
+      double h2osoi_liqvol[ELMO_NLEVTOT];
+      elmo_sms_calc_volumetric_h2oliq(eff_porosity, h2osoi_liq, dz, h2osoi_liqvol);
+      elmo_sms_calc_root_moist_stress(h2osoi_liqvol, rootfr, t_soisno, tc_stress, sucsat, watsat, bsw, smpso, smpsc,
+                                      eff_porosity, altmax_indx, altmax_lastyear_indx, rootr, btran);
+      double lt = dmin(elai + esai, tlsai_crit);
+      double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
+      *displa *= egvf;
+      *z0mv = exp(egvf * log(*z0mv) + (1.0 - egvf) * log(z0mg));
+      *z0hv = *z0mv;
+      *z0qv = *z0mv;
+      w->air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * forc_lwrad;
+      w->bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
+      w->cir = emv * emg * STEBOL;
+      double deldT;
+      elmo_qsat(*t_veg, forc_pbot, &w->el, &deldT, &w->qsatl, &w->qsatldT);
+      w->taf = (t_grnd + thm) / 2.0;
+      w->qaf = (forc_q + qg) / 2.0;
+      w->ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+      double dth = thm - w->taf;
+      double dqh = forc_q - w->qaf;
+      w->delq = qg - w->qaf;
+      double dthv = dth * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * dqh;
+      w->zldis = forc_hgt_u_patch - *displa;
+      if (!(w->zldis >= 0.0)) err |= ELMO_ERR_CANFLX_FORC_HGT;
+      elmo_fv_monin_obukhov_length(w->ur, thv, dthv, w->zldis, *z0mv, &w->um, &w->obu);
+    }
+  }
+  return err;
+}
+
+/* :187-452 stability_iteration.  niter (may be NULL) reports itlef, a diagnostic the parity tests use
+ * to tell "same iteration count" from amplified rounding. */
+unsigned elmo_cf_stability_iteration(const elmo_land *L, double dtime, int snl, int frac_veg_nosno, double frac_sno,
+                                     double forc_hgt_u_patch, double forc_hgt_t_patch, double forc_hgt_q_patch,
+                                     double fwet, double fdry, double laisun, double laisha, double forc_rho,
+                                     double snow_depth, double soilbeta, double frac_h2osfc, double t_h2osfc,
+                                     double sabv, double h2ocan, double htop, const double *t_soisno, double displa,
+                                     double elai, double esai, double t_grnd, double forc_pbot, double forc_q,
+                                     double forc_th, double z0mg, double z0mv, double z0hv, double z0qv, double thm,
+                                     double thv, double qg, const elmo_pft_psn *psn_pft, int nrad, double t10,
+                                     const double *tlai_z, double vcmaxcintsha, double vcmaxcintsun,
+                                     const double *parsha_z, const double *parsun_z, const double *laisha_z,
+                                     const double *laisun_z, double forc_pco2, double forc_po2, double *btran,
+                                     double *qflx_tran_veg, double *qflx_evap_veg, double *eflx_sh_veg,
+                                     elmo_cf_scratch *w, double *t_veg, int *niter)
+{
+  const int nlevsno = ELMO_NLEVSNO;
+  const double btran0 = 0.0;
+  const double beta = 1.0;
+  const double zii = 1000.0;
+  const double ria = 0.5;
+  const double dlemin = 0.1;
+  const double dtmin = 0.01;
+  unsigned err = 0;
+  if (niter) *niter = 0;
+  if (!L->lakpoi && !L->urbpoi && frac_veg_nosno != 0) {
+    int stop = 0;
+    int itmax = 40;
+    int itmin = 2;
+    int itlef = 0;
+    int nmozsgn = 0;
+    double del = 0.0;
+    double efeb = 0.0;
+    double obuold = 0.0;
+    double ustar, del2, uaf, cf, rb, ram, rah[2], raw[2];
+    double csoilcn, csoilb, ri, ricsoilc, ww, svpts, eah;
+    double wta, wtl, wtshi, wtg0, wtga, wtsqi, wtgq0, wtgaq;
+    double snow_depth_c, fsno_dl, elai_dl, rdl, rppdry, efpot, rpp;
+    double dc1, dc2, efsh, erre, errv, efe, efeold, lw_grnd, dels, ecidif;
+    double tstar, qstar, thvstar, wc, zeta, wtaq, wtlq, dele, det, deldT;
+    double rssun, rssha;
+    double ci_z[ELMO_NLEVCAN] = {0.0};
+
+    while (itlef <= itmax && !stop) {
+      elmo_fv_wind(forc_hgt_u_patch, displa, w->um, w->obu, z0mv, &ustar);
+      elmo_fv_temp(forc_hgt_t_patch, displa, w->obu, z0hv, &w->temp1);
+      elmo_fv_humidity(forc_hgt_q_patch, forc_hgt_t_patch, displa, w->obu, z0hv, z0qv, w->temp1, &w->temp2);
+      elmo_fv_temp2m(w->obu, z0hv, &w->temp12m);
+      elmo_fv_humidity2m(w->obu, z0hv, z0qv, w->temp12m, &w->temp22m);
+
+      w->tlbef = *t_veg;
+      del2 = del;
+      ram = 1.0 / (ustar * ustar / w->um);
+      rah[0] = 1.0 / (w->temp1 * ustar);
+      raw[0] = 1.0 / (w->temp2 * ustar);
+      uaf = w->um * sqrt(1.0 / (ram * w->um));
+      cf = 0.01 / (sqrt(uaf) * sqrt(psn_pft->dleaf));
+      rb = 1.0 / (cf * uaf);
+
+      ww = exp(-(elai + esai));
+      csoilb = (VKC / (0.13 * pow((z0mg * uaf / 1.5e-5), 0.45)));
+      ri = (GRAV * htop * (w->taf - t_grnd)) / (w->taf * pow(uaf, 2.0));
+      if ((w->taf - t_grnd) > 0.0) {
+        ricsoilc = CSOILC / (1.0 + ria * dmin(ri, 10.0));
+        csoilcn = csoilb * ww + ricsoilc * (1.0 - ww);
+      } else {
+        csoilcn = csoilb * ww + CSOILC * (1.0 - ww);
+      }
+      rah[1] = 1.0 / (csoilcn * uaf);
+      raw[1] = rah[1];
+      svpts = w->el;
+      eah = forc_pbot * w->qaf / 0.622;
+
+      if (L->vtype == pft_nsoybean || L->vtype == pft_nsoybeanirrig) {
+        *btran = dmin(1.0, *btran * 1.25);
+      }
+      err |= elmo_psn_photosynthesis(psn_pft, nrad, forc_pbot, *t_veg, t10, svpts, eah, forc_po2, forc_pco2, rb,
+                                     *btran, w->dayl_factor, thm, tlai_z, vcmaxcintsun, parsun_z, laisun_z, ci_z,
+                                     &rssun);
+      if (L->vtype == pft_nsoybean || L->vtype == pft_nsoybeanirrig) {
+        *btran = dmin(1.0, *btran * 1.25);
+      }
+      err |= elmo_psn_photosynthesis(psn_pft, nrad, forc_pbot, *t_veg, t10, svpts, eah, forc_po2, forc_pco2, rb,
+                                     *btran, w->dayl_factor, thm, tlai_z, vcmaxcintsha, parsha_z, laisha_z, ci_z,
+                                     &rssha);
+
+      wta = 1.0 / rah[0];
+      wtl = (elai + esai) / rb;
+      w->wtg = 1.0 / rah[1];
+      wtshi = 1.0 / (wta + wtl + w->wtg);
+      w->wtl0 = wtl * wtshi;
+      wtg0 = w->wtg * wtshi;
+      w->wta0 = wta * wtshi;
+      wtga = w->wta0 + wtg0;
+      w->wtal = w->wta0 + w->wtl0;
+
+      if (fdry > 0.0) {
+        rppdry = fdry * rb * (laisun / (rb + rssun) + laisha / (rb + rssha)) / elai;
+      } else {
+        rppdry = 0.0;
+      }
+      efpot = forc_rho * wtl * (w->qsatl - w->qaf);
+      if (efpot > 0.0) {
+        if (*btran > btran0) {
+          *qflx_tran_veg = efpot * rppdry;
+          rpp = rppdry + fwet;
+        } else {
+          rpp = fwet;
+          *qflx_tran_veg = 0.0;
+        }
+        rpp = dmin(rpp, (*qflx_tran_veg + h2ocan / dtime) / efpot);
+      } else {
+        rpp = 1.0;
+        *qflx_tran_veg = 0.0;
+      }
+
+      wtaq = frac_veg_nosno / raw[0];
+      wtlq = frac_veg_nosno * (elai + esai) / rb * rpp;
+      snow_depth_c = 0.05;
+      fsno_dl = snow_depth / snow_depth_c;
+      elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
+      rdl = (1.0 - exp(-elai_dl)) / (0.004 * uaf);
+      if (w->delq < 0.0) {
+        w->wtgq = frac_veg_nosno / (raw[1] + rdl);
+      } else {
+        w->wtgq = soilbeta * frac_veg_nosno / (raw[1] + rdl);
+      }
+      wtsqi = 1.0 / (wtaq + wtlq + w->wtgq);
+      wtgq0 = w->wtgq * wtsqi;
+      w->wtlq0 = wtlq * wtsqi;
+      w->wtaq0 = wtaq * wtsqi;
+      wtgaq = w->wtaq0 + wtgq0;
+      w->wtalq = w->wtaq0 + w->wtlq0;
+      dc1 = forc_rho * CPAIR * wtl;
+      dc2 = HVAP * forc_rho * wtlq;
+      efsh = dc1 * (wtga * *t_veg - wtg0 * t_grnd - w->wta0 * thm);
+      efe = dc2 * (wtgaq * w->qsatl - wtgq0 * qg - w->wtaq0 * forc_q);
+
+      erre = 0.0;
+      if ((efe * efeb) < 0.0) {
+        efeold = efe;
+        efe = 0.1 * efeold;
+        erre = efe - efeold;
+      }
+      lw_grnd = (frac_sno * pow(t_soisno[nlevsno - snl], 4.0) +
+                 (1.0 - frac_sno - frac_h2osfc) * pow(t_soisno[nlevsno], 4.0) + frac_h2osfc * pow(t_h2osfc, 4.0));
+      w->dt_veg = (sabv + w->air + w->bir * pow(*t_veg, 4.0) + w->cir * lw_grnd - efsh - efe) /
+                  (-4.0 * w->bir * pow(*t_veg, 3.0) + dc1 * wtga + dc2 * wtgaq * w->qsatldT);
+      *t_veg = w->tlbef + w->dt_veg;
+      dels = w->dt_veg;
+      del = fabs(dels);
+      errv = 0.0;
+      if (del > 1.0) {
+        w->dt_veg = dels / del;
+        *t_veg = w->tlbef + w->dt_veg;
+        errv = sabv + w->air + w->bir * pow(w->tlbef, 3.0) * (w->tlbef + 4.0 * w->dt_veg) + w->cir * lw_grnd -
+               (efsh + dc1 * wtga * w->dt_veg) - (efe + dc2 * wtgaq * w->qsatldT * w->dt_veg);
+      }
+      efpot = forc_rho * wtl * (wtgaq * (w->qsatl + w->qsatldT * w->dt_veg) - wtgq0 * qg - w->wtaq0 * forc_q);
+      *qflx_evap_veg = rpp * efpot;
+      ecidif = 0.0;
+      if (efpot > 0.0 && *btran > btran0) {
+        *qflx_tran_veg = efpot * rppdry;
+      } else {
+        *qflx_tran_veg = 0.0;
+      }
+      ecidif = dmax(0.0, *qflx_evap_veg - *qflx_tran_veg - h2ocan / dtime);
+      *qflx_evap_veg = dmin(*qflx_evap_veg, *qflx_tran_veg + h2ocan / dtime);
+      *eflx_sh_veg = efsh + dc1 * wtga * w->dt_veg + errv + erre + HVAP * ecidif;
+      elmo_qsat(*t_veg, forc_pbot, &w->el, &deldT, &w->qsatl, &w->qsatldT);
+
+      w->taf = wtg0 * t_grnd + w->wta0 * thm + w->wtl0 * *t_veg;
+      w->qaf = w->wtlq0 * w->qsatl + wtgq0 * qg + forc_q * w->wtaq0;
+      w->dth = thm - w->taf;
+      w->dqh = forc_q - w->qaf;
+      w->delq = w->wtalq * qg - w->wtlq0 * w->qsatl - w->wtaq0 * forc_q;
+      tstar = w->temp1 * w->dth;
+      qstar = w->temp2 * w->dqh;
+      thvstar = tstar * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * qstar;
+      zeta = w->zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * thv);
+      if (zeta >= 0.0) {
+        zeta = dmin(2.0, dmax(zeta, 0.01));
+        w->um = dmax(w->ur, 0.1);
+      } else {
+        zeta = dmax(-100.0, dmin(zeta, -0.01));
+        wc = beta * pow((-GRAV * ustar * thvstar * zii / thv), 0.333);
+        w->um = sqrt(w->ur * w->ur + wc * wc);
+      }
+      w->obu = w->zldis / zeta;
+      if (obuold * w->obu < 0.0) {
+        nmozsgn += 1;
+      }
+      if (nmozsgn >= 4) {
+        w->obu = w->zldis / (-0.01);
+      }
+      obuold = w->obu;
+
+      itlef += 1;
+      if (itlef > itmin) {
+        dele = fabs(efe - efeb);
+        efeb = efe;
+        det = dmax(del, del2);
+        if ((det < dtmin) && (dele < dlemin)) {
+          stop = 1;
+        }
+      }
+    }
+    if (niter) *niter = itlef;
+  }
+  return err;
+}
+
+/* :456-540 compute_flux */
+void elmo_cf_compute_flux(const elmo_land *L, double dtime, int snl, int frac_veg_nosno, double frac_sno,
+                          const double *t_soisno, double frac_h2osfc, double t_h2osfc, double sabv, double qg_snow,
+                          double qg_soil, double qg_h2osfc, double dqgdT, double htvp, const elmo_cf_scratch *w,
+                          double t_veg, double t_grnd, double forc_pbot, double qflx_tran_veg, double qflx_evap_veg,
+                          double eflx_sh_veg, double forc_q, double forc_rho, double thm, double emv, double emg,
+                          double forc_lwrad, double *h2ocan, double *eflx_sh_grnd, double *eflx_sh_snow,
+                          double *eflx_sh_soil, double *eflx_sh_h2osfc, double *qflx_evap_soi, double *qflx_ev_snow,
+                          double *qflx_ev_soil, double *qflx_ev_h2osfc, double *dlrad, double *ulrad, double *cgrnds,
+                          double *cgrndl, double *cgrnd, double *t_ref2m, double *q_ref2m, double *rh_ref2m)
+{
+  const int nlevsno = ELMO_NLEVSNO;
+  (void)sabv;
+  (void)eflx_sh_veg;
+  if (!L->lakpoi) {
+    *cgrnd = 0.0;
+    *cgrnds = 0.0;
+    *cgrndl = 0.0;
+  }
+  if (!L->lakpoi && !L->urbpoi && frac_veg_nosno != 0) {
+    double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
+    double lw_grnd = (frac_sno * pow(t_soisno[nlevsno - snl], 4.0) +
+                      (1.0 - frac_sno - frac_h2osfc) * pow(t_soisno[nlevsno], 4.0) + frac_h2osfc * pow(t_h2osfc, 4.0));
+    /* the reference also forms an energy-balance residual "err" here and never uses it */
+    double delt = w->wtal * t_grnd - w->wtl0 * t_veg - w->wta0 * thm;
+    *eflx_sh_grnd = CPAIR * forc_rho * w->wtg * delt;
+    double delt_snow = w->wtal * t_soisno[nlevsno - snl] - w->wtl0 * t_veg - w->wta0 * thm;
+    *eflx_sh_snow = CPAIR * forc_rho * w->wtg * delt_snow;
+    double delt_soil = w->wtal * t_soisno[nlevsno] - w->wtl0 * t_veg - w->wta0 * thm;
+    *eflx_sh_soil = CPAIR * forc_rho * w->wtg * delt_soil;
+    double delt_h2osfc = w->wtal * t_h2osfc - w->wtl0 * t_veg - w->wta0 * thm;
+    *eflx_sh_h2osfc = CPAIR * forc_rho * w->wtg * delt_h2osfc;
+    *qflx_evap_soi = forc_rho * w->wtgq * w->delq;
+    double delq_snow = w->wtalq * qg_snow - w->wtlq0 * w->qsatl - w->wtaq0 * forc_q;
+    *qflx_ev_snow = forc_rho * w->wtgq * delq_snow;
+    double delq_soil = w->wtalq * qg_soil - w->wtlq0 * w->qsatl - w->wtaq0 * forc_q;
+    *qflx_ev_soil = forc_rho * w->wtgq * delq_soil;
+    double delq_h2osfc = w->wtalq * qg_h2osfc - w->wtlq0 * w->qsatl - w->wtaq0 * forc_q;
+    *qflx_ev_h2osfc = forc_rho * w->wtgq * delq_h2osfc;
+    *t_ref2m = thm + w->temp1 * w->dth * (1.0 / w->temp12m - 1.0 / w->temp1);
+    *q_ref2m = forc_q + w->temp2 * w->dqh * (1.0 / w->temp22m - 1.0 / w->temp2);
+    elmo_qsat(*t_ref2m, forc_pbot, &e_ref2m, &de2mdT, &qsat_ref2m, &dqsat2mdT);
+    *rh_ref2m = dmin(100.0, (*q_ref2m / qsat_ref2m) * 100.0);
+    *dlrad = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * pow(w->tlbef, 3.0) * (w->tlbef + 4.0 * w->dt_veg);
+    *ulrad = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * forc_lwrad +
+              emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(w->tlbef, 3.0) * (w->tlbef + 4.0 * w->dt_veg) +
+              emg * (1.0 - emv) * STEBOL * lw_grnd);
+    *cgrnds += CPAIR * forc_rho * w->wtg * w->wtal;
+    *cgrndl += forc_rho * w->wtgq * w->wtalq * dqgdT;
+    *cgrnd = *cgrnds + *cgrndl * htvp;
+    *h2ocan = dmax(0.0, *h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
+  }
+}

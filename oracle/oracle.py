@@ -1,0 +1,298 @@
+"""ctypes front-end for the parity oracle (TEST INFRASTRUCTURE - see oracle/elm_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+
+  Oracle            libelmoracle.so - the plain-C restatement (OpenMP over columns)
+  Reference         _ref/libelmref.so - the reference's own headers compiled by oracle/Makefile
+                    (present only where it was built in the build container; None otherwise)
+  OracleState       the [col][lev] state container both of them operate on
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "..", "tests", "golden")
+
+KIND_DTYPE = {0: np.float64, 1: np.int32, 2: np.uint8}
+
+PSN_FIELDS = (
+    "fnr act25 kcha koha cpha vcmaxha jmaxha tpuha lmrha vcmaxhd jmaxhd tpuhd lmrhd lmrse qe theta_cj "
+    "bbbopt mbbopt c3psn slatop leafcn flnr fnitr dleaf smpso smpsc tc_stress"
+).split()
+
+SNICAR_TABLES = (
+    [(f"{p}_{s}", 5) for s in ("oc1", "oc2", "dst1", "dst2", "dst3", "dst4") for p in ("ss_alb", "asm_prm", "ext_cff_mss")]
+    + [(f"{p}_snw_{s}", 5 * 1471) for s in ("drc", "dfs") for p in ("ss_alb", "asm_prm", "ext_cff_mss")]
+    + [(f"{p}_{s}", 50) for s in ("bc1", "bc2") for p in ("ss_alb", "asm_prm", "ext_cff_mss")]
+    + [("bcenh", 400)]
+)
+
+
+def build(ref=True):
+    """(Re)build libelmoracle.so and, when the reference is mounted, _ref/libelmref.so."""
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if ref and os.path.isdir("/root/reference/src/physics"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def _load(path):
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+class _Lib:
+    def __init__(self):
+        p = os.path.join(HERE, "libelmoracle.so")
+        if not os.path.exists(p):
+            build(ref=False)
+        self.lib = C.CDLL(p)
+        L = self.lib
+        L.elmo_create.restype = C.c_void_p
+        L.elmo_create.argtypes = [C.c_int64]
+        L.elmo_destroy.argtypes = [C.c_void_p]
+        L.elmo_num_fields.restype = C.c_int
+        L.elmo_field_name.restype = C.c_char_p
+        L.elmo_field_name.argtypes = [C.c_int]
+        L.elmo_field_ptr.restype = C.c_void_p
+        L.elmo_field_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for n in ("snicar", "pft_psn", "pft_alb", "z0mr", "displar", "albsat", "albdry"):
+            f = getattr(L, f"elmo_{n}_ptr")
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_void_p]
+        L.elmo_set_scalars.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_double, C.c_int, C.c_double, C.c_double]
+        L.elmo_set_threads.argtypes = [C.c_int]
+        L.elmo_get_max_threads.restype = C.c_int
+        for n in ("frac_wet", "albedo_snicar", "surface_radiation", "canopy_temperature", "bareground_fluxes"):
+            getattr(L, f"elmo_{n}").argtypes = [C.c_void_p]
+        for n in ("canopy_hydrology", "canopy_fluxes", "timestep7"):
+            getattr(L, f"elmo_{n}").argtypes = [C.c_void_p, C.c_double]
+        L.elmo_canopy_fluxes_given.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 4
+        L.elmo_bareground_fluxes_given.argtypes = [C.c_void_p, C.c_void_p]
+        L.elmo_albedo_snicar_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ref = _load(os.path.join(HERE, "_ref", "libelmref.so"))
+        if self.ref is not None:
+            R = self.ref
+            for n in ("frac_wet", "surface_radiation", "canopy_temperature", "bareground_fluxes", "soil_moist_stress"):
+                getattr(R, f"elmref_{n}").argtypes = [C.c_void_p]
+            R.elmref_canopy_hydrology.argtypes = [C.c_void_p, C.c_double]
+            R.elmref_snicar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            R.elmref_qsat.argtypes = [C.c_int64] + [C.c_void_p] * 6
+            R.elmref_forc_derived.argtypes = [C.c_int64] + [C.c_void_p] * 6
+            R.elmref_friction.argtypes = [C.c_int64] + [C.c_void_p] * 12
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+def field_names():
+    L = lib().lib
+    return [L.elmo_field_name(i).decode() for i in range(L.elmo_num_fields())]
+
+
+def _view(addr, shape, dtype):
+    n = int(np.prod(shape))
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class OracleState:
+    """Column state in the reference's [col][lev] layout; fields are numpy views into C memory."""
+
+    def __init__(self, ncols):
+        self._L = lib()
+        self.ncols = int(ncols)
+        self.ptr = self._L.lib.elmo_create(self.ncols)
+        if not self.ptr:
+            raise MemoryError("elmo_create failed")
+        self.fields = {}
+        self.nlev = {}
+        for name in field_names() + ["err_flags"]:
+            nlev, kind = C.c_int(), C.c_int()
+            addr = self._L.lib.elmo_field_ptr(self.ptr, name.encode(), C.byref(nlev), C.byref(kind))
+            dt = np.uint32 if name == "err_flags" else KIND_DTYPE[kind.value]
+            shape = (self.ncols, nlev.value) if nlev.value > 1 else (self.ncols,)
+            self.fields[name] = _view(addr, shape, dt) if self.ncols > 0 else np.zeros(shape, dt)
+            self.nlev[name] = nlev.value
+        L = self._L.lib
+        self.pft_psn = _view(L.elmo_pft_psn_ptr(self.ptr), (25, 27), np.float64)
+        self.pft_alb = _view(L.elmo_pft_alb_ptr(self.ptr), (25, 9), np.float64)
+        self.z0mr = _view(L.elmo_z0mr_ptr(self.ptr), (25,), np.float64)
+        self.displar = _view(L.elmo_displar_ptr(self.ptr), (25,), np.float64)
+        self.albsat = _view(L.elmo_albsat_ptr(self.ptr), (20, 2), np.float64)
+        self.albdry = _view(L.elmo_albdry_ptr(self.ptr), (20, 2), np.float64)
+        self.snicar = {}
+        off = L.elmo_snicar_ptr(self.ptr)
+        for name, n in SNICAR_TABLES:
+            self.snicar[name] = _view(off, (n,), np.float64)
+            off += n * 8
+        self.scalars = dict(ltype=1, ctype=0, vtype=2, urbpoi=0, lakpoi=0, dewmx=0.1, oldfflag=1, dayl=0.0, max_dayl=0.0)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._L.lib.elmo_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    def __getitem__(self, name):
+        return self.fields[name]
+
+    def set_scalars(self, **kw):
+        self.scalars.update(kw)
+        s = self.scalars
+        self._L.lib.elmo_set_scalars(
+            self.ptr, int(s["ltype"]), int(s["ctype"]), int(s["vtype"]), int(s["urbpoi"]), int(s["lakpoi"]),
+            float(s["dewmx"]), int(s["oldfflag"]), float(s["dayl"]), float(s["max_dayl"]),
+        )
+
+    def load_params(self, pft=None, optics=None):
+        """Fill the shared tables from the committed fixtures (tests/golden/pft_params.npz, SnowOptics.npz)."""
+        pft = pft if pft is not None else np.load(os.path.join(GOLDEN, "pft_params.npz"))
+        optics = optics if optics is not None else np.load(os.path.join(GOLDEN, "SnowOptics.npz"))
+        set_pft_tables(self.pft_psn, self.pft_alb, self.z0mr, self.displar, pft)
+        for name, n in SNICAR_TABLES:
+            self.snicar[name][:] = np.asarray(optics[name], dtype=np.float64).reshape(-1)[:n]
+
+    def copy_from(self, other):
+        for k, v in other.fields.items():
+            self.fields[k][...] = v
+        self.pft_psn[...] = other.pft_psn
+        self.pft_alb[...] = other.pft_alb
+        self.z0mr[...] = other.z0mr
+        self.displar[...] = other.displar
+        self.albsat[...] = other.albsat
+        self.albdry[...] = other.albdry
+        for k in self.snicar:
+            self.snicar[k][...] = other.snicar[k]
+        self.set_scalars(**other.scalars)
+
+    def clone(self):
+        o = OracleState(self.ncols)
+        o.copy_from(self)
+        return o
+
+    # -- the L3 wrappers ------------------------------------------------------------------------
+    def frac_wet(self):
+        self._L.lib.elmo_frac_wet(self.ptr)
+
+    def albedo_snicar(self):
+        self._L.lib.elmo_albedo_snicar(self.ptr)
+
+    def canopy_hydrology(self, dt):
+        self._L.lib.elmo_canopy_hydrology(self.ptr, float(dt))
+
+    def surface_radiation(self):
+        self._L.lib.elmo_surface_radiation(self.ptr)
+
+    def canopy_temperature(self):
+        self._L.lib.elmo_canopy_temperature(self.ptr)
+
+    def bareground_fluxes(self):
+        self._L.lib.elmo_bareground_fluxes(self.ptr)
+
+    def canopy_fluxes(self, dt):
+        self._L.lib.elmo_canopy_fluxes(self.ptr, float(dt))
+
+    def bareground_fluxes_given(self, rho):
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        self._L.lib.elmo_bareground_fluxes_given(self.ptr, rho.ctypes.data)
+
+    def albedo_snicar_ex(self):
+        """-> (fabd_sun, fabd_sha): the wrapper-local arrays the reference never stores in the state."""
+        sun = np.zeros((self.ncols, 2))
+        sha = np.zeros((self.ncols, 2))
+        self._L.lib.elmo_albedo_snicar_ex(self.ptr, sun.ctypes.data, sha.ctypes.data)
+        return sun, sha
+
+    def canopy_fluxes_given(self, dt, rho=None, po2=None, pco2=None, want_niter=False):
+        """L2-level entry: forcing-derived scalars handed in (as test_CanFlux.cc does) instead of derived."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (rho, po2, pco2)]
+        niter = np.zeros(self.ncols, dtype=np.int32) if want_niter else None
+        self._L.lib.elmo_canopy_fluxes_given(
+            self.ptr, float(dt), *[None if a is None else a.ctypes.data for a in arrs],
+            None if niter is None else niter.ctypes.data,
+        )
+        return niter
+
+    def timestep7(self, dt):
+        self._L.lib.elmo_timestep7(self.ptr, float(dt))
+
+
+def set_pft_tables(psn, alb, z0mr, displar, pft):
+    """PFTData::get_pft_psn / get_pft_alb wiring (src/data/pft_data_impl.hh:64-116) for all 25 PFTs."""
+    for j, name in enumerate(PSN_FIELDS):
+        v = np.asarray(pft[name], dtype=np.float64).reshape(-1)
+        psn[:, j] = v[0] if name == "tc_stress" else v[:25]
+    for j, name in enumerate(
+        ["rholvis", "rholnir", "rhosvis", "rhosnir", "taulvis", "taulnir", "tausvis", "tausnir", "xl"]
+    ):
+        alb[:, j] = np.asarray(pft[name], dtype=np.float64).reshape(-1)[:25]
+    z0mr[:] = np.asarray(pft["z0mr"]).reshape(-1)[:25]
+    displar[:] = np.asarray(pft["displar"]).reshape(-1)[:25]
+
+
+def have_ref():
+    return lib().ref is not None
+
+
+class Reference:
+    """The compiled reference headers (oracle/_ref/libelmref.so) driven on an OracleState."""
+
+    def __init__(self):
+        self.R = lib().ref
+        if self.R is None:
+            raise RuntimeError("oracle/_ref/libelmref.so not built (reference not mounted here)")
+
+    def frac_wet(self, S):
+        self.R.elmref_frac_wet(S.ptr)
+
+    def canopy_hydrology(self, S, dt):
+        self.R.elmref_canopy_hydrology(S.ptr, float(dt))
+
+    def surface_radiation(self, S):
+        self.R.elmref_surface_radiation(S.ptr)
+
+    def canopy_temperature(self, S):
+        self.R.elmref_canopy_temperature(S.ptr)
+
+    def bareground_fluxes(self, S):
+        self.R.elmref_bareground_fluxes(S.ptr)
+
+    def soil_moist_stress(self, S):
+        self.R.elmref_soil_moist_stress(S.ptr)
+
+    def snicar(self, S):
+        d = np.zeros((S.ncols, 6, 2))
+        i = np.zeros((S.ncols, 6, 2))
+        self.R.elmref_snicar(S.ptr, d.ctypes.data, i.ctypes.data)
+        return d, i
+
+    def qsat(self, T, p):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        out = [np.zeros_like(T) for _ in range(4)]
+        self.R.elmref_qsat(T.size, T.ctypes.data, p.ctypes.data, *[o.ctypes.data for o in out])
+        return out
+
+    def forc_derived(self, pbot, qbot, tbot):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pbot, qbot, tbot)]
+        out = [np.zeros_like(a[0]) for _ in range(3)]
+        self.R.elmref_forc_derived(a[0].size, *[x.ctypes.data for x in a], *[o.ctypes.data for o in out])
+        return out
+
+    def friction(self, **kw):
+        names = "ur thv dthv zldis z0m z0h z0q hgt_u hgt_t hgt_q displa".split()
+        a = [np.ascontiguousarray(kw[n], dtype=np.float64) for n in names]
+        out = np.zeros((a[0].size, 7))
+        self.R.elmref_friction(a[0].size, *[x.ctypes.data for x in a], out.ctypes.data)
+        return out

@@ -1,0 +1,310 @@
+// ref_harness.cc - drives the REFERENCE's own physics headers (included from where they lie under
+// /root/reference at build time; nothing is copied) behind the oracle's state container, so that
+// tests can run reference and restatement on identical inputs.  Built only in the build container
+// by oracle/Makefile into oracle/_ref/libelmref.so (git-ignored; travels to the GPU box as a binary).
+//
+// TEST INFRASTRUCTURE ONLY - see elm_oracle.h.
+//
+// Covered: every hot-path header that compiles without netcdf-c:
+//   canopy_hydrology.h  surface_radiation.h  canopy_temperature.h (+qsat.h, surface_resistance.h)
+//   bareground_fluxes.h (+friction_velocity.h)  snow_snicar.h  soil_moist_stress.h  atm_physics.h
+// Not covered (unbuildable here: pft_data.h -> read_input.hh -> read_netcdf.hh -> netcdf.h):
+//   canopy_fluxes.h  photosynthesis.h  surface_albedo.h
+// The loops below follow the argument wiring of driver/kokkos/*_kokkos.cc (cited per function).
+
+#include "array.hh"
+#include "elm_constants.h"
+#include "land_data.h"
+
+#include "atm_physics.h"
+#include "bareground_fluxes.h"
+#include "canopy_hydrology.h"
+#include "canopy_temperature.h"
+#include "friction_velocity.h"
+#include "qsat.h"
+#include "snow_snicar.h"
+#include "soil_moist_stress.h"
+#include "surface_radiation.h"
+
+#include "elm_oracle.h"
+
+#include <cstring>
+#include <exception>
+
+using AD1 = ELM::Array<double, 1>;
+using AI1 = ELM::Array<int, 1>;
+using AD2 = ELM::Array<double, 2>;
+using AD3 = ELM::Array<double, 3>;
+
+static ELM::LandType land_of(const elmo_state* S)
+{
+  ELM::LandType L;
+  L.ltype = S->land.ltype;
+  L.ctype = S->land.ctype;
+  L.vtype = S->land.vtype;
+  L.urbpoi = S->land.urbpoi != 0;
+  L.lakpoi = S->land.lakpoi != 0;
+  return L;
+}
+
+#define V(f, n) AD1(n, S->f + (size_t)c * (n))
+static const uint32_t REF_THREW = 1u << 31;
+
+extern "C" {
+
+// canopy_hydrology_kokkos.cc:98-112
+void elmref_frac_wet(elmo_state* S)
+{
+  const ELM::LandType L = land_of(S);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    ELM::canopy_hydrology::fraction_wet(L, S->frac_veg_nosno[c], S->dewmx, S->elai[c], S->esai[c], S->h2ocan[c],
+                                        S->fwet[c], S->fdry[c]);
+  }
+}
+
+// canopy_hydrology_kokkos.cc:7-95
+void elmref_canopy_hydrology(elmo_state* S, double dt)
+{
+  const ELM::LandType L = land_of(S);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double qflx_irrig = 0.0;
+    double qflx_candrip = 0.0, qflx_through_snow = 0.0, qflx_through_rain = 0.0, fracsnow = 0.0, fracrain = 0.0;
+    ELM::canopy_hydrology::interception(L, S->frac_veg_nosno[c], S->forc_rain[c], S->forc_snow[c], S->dewmx,
+                                        S->elai[c], S->esai[c], dt, S->h2ocan[c], qflx_candrip, qflx_through_snow,
+                                        qflx_through_rain, fracsnow, fracrain);
+    ELM::canopy_hydrology::ground_flux(L, S->do_capsnow[c], S->frac_veg_nosno[c], S->forc_rain[c], S->forc_snow[c],
+                                       qflx_irrig, qflx_candrip, qflx_through_snow, qflx_through_rain, fracsnow,
+                                       fracrain, S->qflx_snwcp_liq[c], S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c],
+                                       S->qflx_rain_grnd[c]);
+    ELM::canopy_hydrology::snow_init(L, dt, S->do_capsnow[c], S->oldfflag, S->forc_tbot[c], S->t_grnd[c],
+                                     S->qflx_snow_grnd[c], S->qflx_snow_melt[c], S->n_melt[c], S->snow_depth[c],
+                                     S->h2osno[c], S->int_snow[c], V(swe_old, 5), V(h2osoi_liq, 20), V(h2osoi_ice, 20),
+                                     V(t_soisno, 20), V(frac_iceold, 20), S->snl[c], V(dz, 20), V(zsoi, 20),
+                                     V(zisoi, 21), V(snw_rds, 5), S->frac_sno_eff[c], S->frac_sno[c]);
+    ELM::canopy_hydrology::fraction_h2osfc(L, S->micro_sigma[c], S->h2osno[c], S->h2osfc[c], V(h2osoi_liq, 20),
+                                           S->frac_sno[c], S->frac_sno_eff[c], S->frac_h2osfc[c]);
+  }
+}
+
+// surface_radiation_kokkos.cc:7-97 (library is built with -DNDEBUG: the layer-sum assert of
+// surface_radiation_impl.hh:173 would otherwise abort the test process)
+void elmref_surface_radiation(elmo_state* S)
+{
+  const ELM::LandType L = land_of(S);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double trd_[2] = {0.0, 0.0}, tri_[2] = {0.0, 0.0};
+    AD1 trd(2, trd_), tri(2, tri_);
+    ELM::surface_radiation::canopy_sunshade_fractions(L, S->nrad[c], S->elai[c], V(tlai_z, 1), V(fsun_z, 1),
+                                                      V(forc_solad, 2), V(forc_solai, 2), V(fabd_sun_z, 1),
+                                                      V(fabd_sha_z, 1), V(fabi_sun_z, 1), V(fabi_sha_z, 1),
+                                                      V(parsun_z, 1), V(parsha_z, 1), V(laisun_z, 1), V(laisha_z, 1),
+                                                      S->laisun[c], S->laisha[c]);
+    ELM::surface_radiation::initialize_flux(L, S->sabg_soil[c], S->sabg_snow[c], S->sabg[c], S->sabv[c], S->fsa[c],
+                                            V(sabg_lyr, 6));
+    ELM::surface_radiation::total_absorbed_radiation(L, S->snl[c], V(ftdd, 2), V(ftid, 2), V(ftii, 2), V(forc_solad, 2),
+                                                     V(forc_solai, 2), V(fabd, 2), V(fabi, 2), V(albsod, 2),
+                                                     V(albsoi, 2), V(albsnd, 2), V(albsni, 2), V(albgrd, 2),
+                                                     V(albgri, 2), S->sabv[c], S->fsa[c], S->sabg[c], S->sabg_soil[c],
+                                                     S->sabg_snow[c], trd, tri);
+    ELM::surface_radiation::layer_absorbed_radiation(L, S->snl[c], S->sabg[c], S->sabg_snow[c], S->snow_depth[c],
+                                                     V(flx_absdv, 6), V(flx_absdn, 6), V(flx_absiv, 6), V(flx_absin, 6),
+                                                     trd, tri, V(sabg_lyr, 6));
+    ELM::surface_radiation::reflected_radiation(L, V(albd, 2), V(albi, 2), V(forc_solad, 2), V(forc_solai, 2),
+                                                S->fsr[c]);
+  }
+}
+
+// canopy_temperature_kokkos.cc:6-131
+void elmref_canopy_temperature(elmo_state* S)
+{
+  const ELM::LandType L = land_of(S);
+  AD1 displar(ELMO_MXPFT, S->displar), z0mr(ELMO_MXPFT, S->z0mr);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double qred = 0.0, hr = 0.0, soilalpha = 0.0;
+    bool veg_active = S->veg_active[c] != 0;
+    ELM::canopy_temperature::old_ground_temp(L, S->t_h2osfc[c], V(t_soisno, 20), S->t_h2osfc_bef[c], V(tssbef, 20));
+    ELM::canopy_temperature::ground_temp(L, S->snl[c], S->frac_sno_eff[c], S->frac_h2osfc[c], S->t_h2osfc[c],
+                                         V(t_soisno, 20), S->t_grnd[c]);
+    ELM::canopy_temperature::calc_soilalpha(L, S->frac_sno[c], S->frac_h2osfc[c], V(h2osoi_liq, 20), V(h2osoi_ice, 20),
+                                            V(dz, 20), V(t_soisno, 20), V(watsat, 15), V(sucsat, 15), V(bsw, 15),
+                                            V(watdry, 15), V(watopt, 15), qred, hr, soilalpha);
+    ELM::canopy_temperature::calc_soilbeta(L, S->frac_sno[c], S->frac_h2osfc[c], V(watsat, 15), V(watfc, 15),
+                                           V(h2osoi_liq, 20), V(h2osoi_ice, 20), V(dz, 20), S->soilbeta[c]);
+    ELM::canopy_temperature::humidities(L, S->snl[c], S->forc_qbot[c], S->forc_pbot[c], S->t_h2osfc[c], S->t_grnd[c],
+                                        S->frac_sno[c], S->frac_sno_eff[c], S->frac_h2osfc[c], qred, hr,
+                                        V(t_soisno, 20), S->qg_snow[c], S->qg_soil[c], S->qg[c], S->qg_h2osfc[c],
+                                        S->dqgdT[c]);
+    ELM::canopy_temperature::ground_properties(L, S->snl[c], S->frac_sno[c], S->forc_thbot[c], S->forc_qbot[c],
+                                               S->elai[c], S->esai[c], S->htop[c], displar, z0mr, V(h2osoi_liq, 20),
+                                               V(h2osoi_ice, 20), S->emg[c], S->emv[c], S->htvp[c], S->z0mg[c],
+                                               S->z0hg[c], S->z0qg[c], S->z0mv[c], S->z0hv[c], S->z0qv[c], S->thv[c],
+                                               S->z0m[c], S->displa[c]);
+    ELM::canopy_temperature::forcing_height(L, veg_active, S->frac_veg_nosno[c], S->z0m[c], S->z0mg[c],
+                                            S->forc_tbot[c], S->displa[c], S->forc_hgt_u_patch[c],
+                                            S->forc_hgt_t_patch[c], S->forc_hgt_q_patch[c], S->thm[c]);
+    ELM::canopy_temperature::init_energy_fluxes(L, S->eflx_sh_tot[c], S->eflx_lh_tot[c], S->eflx_sh_veg[c],
+                                                S->qflx_evap_tot[c], S->qflx_evap_veg[c], S->qflx_tran_veg[c]);
+  }
+}
+
+// bareground_fluxes_kokkos.cc:7-123
+void elmref_bareground_fluxes(elmo_state* S)
+{
+  const ELM::LandType L = land_of(S);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double zldis = 0.0, displa = 0.0, dth = 0.0, dqh = 0.0, obu = 0.0, ur = 0.0, um = 0.0, temp1 = 0.0, temp2 = 0.0,
+           temp12m = 0.0, temp22m = 0.0, ustar = 0.0;
+    double forc_rho = ELM::atm_forcing_physics::derive_forc_rho(S->forc_pbot[c], S->forc_qbot[c], S->forc_tbot[c]);
+    ELM::bareground_fluxes::initialize_flux(L, S->frac_veg_nosno[c], S->forc_u[c], S->forc_v[c], S->forc_qbot[c],
+                                            S->forc_thbot[c], S->forc_hgt_u_patch[c], S->thm[c], S->thv[c],
+                                            S->t_grnd[c], S->qg[c], S->z0mg[c], S->dlrad[c], S->ulrad[c], zldis, displa,
+                                            dth, dqh, obu, ur, um);
+    ELM::bareground_fluxes::stability_iteration(L, S->frac_veg_nosno[c], S->forc_hgt_t_patch[c],
+                                                S->forc_hgt_u_patch[c], S->forc_hgt_q_patch[c], S->z0mg[c], zldis,
+                                                displa, dth, dqh, ur, S->forc_qbot[c], S->forc_thbot[c], S->thv[c],
+                                                S->z0hg[c], S->z0qg[c], obu, um, temp1, temp2, temp12m, temp22m, ustar);
+    ELM::bareground_fluxes::compute_flux(L, S->frac_veg_nosno[c], S->snl[c], forc_rho, S->soilbeta[c], S->dqgdT[c],
+                                         S->htvp[c], S->t_h2osfc[c], S->qg_snow[c], S->qg_soil[c], S->qg_h2osfc[c],
+                                         V(t_soisno, 20), S->forc_pbot[c], dth, dqh, temp1, temp2, temp12m, temp22m,
+                                         ustar, S->forc_qbot[c], S->thm[c], S->cgrnds[c], S->cgrndl[c], S->cgrnd[c],
+                                         S->eflx_sh_grnd[c], S->eflx_sh_tot[c], S->eflx_sh_snow[c], S->eflx_sh_soil[c],
+                                         S->eflx_sh_h2osfc[c], S->qflx_evap_soi[c], S->qflx_evap_tot[c],
+                                         S->qflx_ev_snow[c], S->qflx_ev_soil[c], S->qflx_ev_h2osfc[c], S->t_ref2m[c],
+                                         S->q_ref2m[c], S->rh_ref2m[c]);
+  }
+}
+
+// The SNICAR half of albedo_kokkos.cc:96-301: both passes (direct, diffuse) of
+// init_timestep -> snow_aerosol_mie_params -> snow_radiative_transfer_solver -> snow_albedo_radiation_factor
+// with the wrapper's zero-filled scratch.  Inputs: coszen, h2osno, snl, h2osoi_liq/ice, snw_rds, cnc_*,
+// albsoi (taken from the state as it stands).  Outputs: S.albsnd, S.albsni and the caller's
+// flx_absd_snw / flx_absi_snw [ncols][6][2] (wrapper-local in the reference).
+void elmref_snicar(elmo_state* S, double* flx_absd_snw_out, double* flx_absi_snw_out)
+{
+  const bool urbpoi = S->land.urbpoi != 0;
+  elmo_snicar* T = &S->snicar;
+#define T1(n) AD1(5, T->n)
+#define TM(n) AD2(5, ELMO_MIE_N, T->n)
+#define TB(n) AD2(10, 5, T->n)
+  AD3 bcenh(8, 10, 5, T->bcenh);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    int snw_rds_lcl_[5] = {0};
+    double h2osoi_ice_lcl_[5] = {0}, h2osoi_liq_lcl_[5] = {0}, albout_lcl_[5] = {0}, flx_slrd_lcl_[5] = {0},
+           flx_slri_lcl_[5] = {0};
+    double flx_abs_lcl_[30] = {0}, mss_[40] = {0}, g_star_[25] = {0}, omega_star_[25] = {0}, tau_star_[25] = {0};
+    double* flx_absd = flx_absd_snw_out + (size_t)c * 12;
+    double* flx_absi = flx_absi_snw_out + (size_t)c * 12;
+    std::memset(flx_absd, 0, 12 * sizeof(double));
+    std::memset(flx_absi, 0, 12 * sizeof(double));
+    // surface_albedo::init_timestep's aerosol wiring (surface_albedo_impl.hh:141-150) cannot be called
+    // (header needs netcdf); it is a plain copy, reproduced here as harness input preparation
+    for (int i = 0; i < 5; i++) {
+      mss_[i * 8 + 0] = S->cnc_bcphi[c * 5 + i];
+      mss_[i * 8 + 1] = S->cnc_bcpho[c * 5 + i];
+      mss_[i * 8 + 4] = S->cnc_dst1[c * 5 + i];
+      mss_[i * 8 + 5] = S->cnc_dst2[c * 5 + i];
+      mss_[i * 8 + 6] = S->cnc_dst3[c * 5 + i];
+      mss_[i * 8 + 7] = S->cnc_dst4[c * 5 + i];
+    }
+    AI1 snw_rds_lcl(5, snw_rds_lcl_);
+    AD1 h2osoi_ice_lcl(5, h2osoi_ice_lcl_), h2osoi_liq_lcl(5, h2osoi_liq_lcl_), albout_lcl(5, albout_lcl_),
+        flx_slrd_lcl(5, flx_slrd_lcl_), flx_slri_lcl(5, flx_slri_lcl_);
+    AD2 flx_abs_lcl(6, 5, flx_abs_lcl_), mss(5, 8, mss_), g_star(5, 5, g_star_), omega_star(5, 5, omega_star_),
+        tau_star(5, 5, tau_star_);
+    int snl_top = 0, snl_btm = 0, flg_nosnl = 0;
+    double mu_not = 0.0;
+    try {
+      for (int flg_slr_in = 1; flg_slr_in <= 2; flg_slr_in++) {
+        AD2 flx_abs(6, 2, flg_slr_in == 1 ? flx_absd : flx_absi);
+        AD1 albout(2, (flg_slr_in == 1 ? S->albsnd : S->albsni) + (size_t)c * 2);
+        ELM::snow_snicar::init_timestep(urbpoi, flg_slr_in, S->coszen[c], S->h2osno[c], S->snl[c], V(h2osoi_liq, 20),
+                                        V(h2osoi_ice, 20), V(snw_rds, 5), snl_top, snl_btm, flx_abs_lcl, flx_abs,
+                                        flg_nosnl, h2osoi_ice_lcl, h2osoi_liq_lcl, snw_rds_lcl, mu_not, flx_slrd_lcl,
+                                        flx_slri_lcl);
+        ELM::snow_snicar::snow_aerosol_mie_params(
+            urbpoi, flg_slr_in, snl_top, snl_btm, S->coszen[c], S->h2osno[c], snw_rds_lcl, h2osoi_ice_lcl,
+            h2osoi_liq_lcl, T1(ss_alb_oc1), T1(asm_prm_oc1), T1(ext_cff_mss_oc1), T1(ss_alb_oc2), T1(asm_prm_oc2),
+            T1(ext_cff_mss_oc2), T1(ss_alb_dst1), T1(asm_prm_dst1), T1(ext_cff_mss_dst1), T1(ss_alb_dst2),
+            T1(asm_prm_dst2), T1(ext_cff_mss_dst2), T1(ss_alb_dst3), T1(asm_prm_dst3), T1(ext_cff_mss_dst3),
+            T1(ss_alb_dst4), T1(asm_prm_dst4), T1(ext_cff_mss_dst4), TM(ss_alb_snw_drc), TM(asm_prm_snw_drc),
+            TM(ext_cff_mss_snw_drc), TM(ss_alb_snw_dfs), TM(asm_prm_snw_dfs), TM(ext_cff_mss_snw_dfs), TB(ss_alb_bc1),
+            TB(asm_prm_bc1), TB(ext_cff_mss_bc1), TB(ss_alb_bc2), TB(asm_prm_bc2), TB(ext_cff_mss_bc2), bcenh, mss,
+            g_star, omega_star, tau_star);
+        ELM::snow_snicar::snow_radiative_transfer_solver(urbpoi, flg_slr_in, flg_nosnl, snl_top, snl_btm, S->coszen[c],
+                                                         S->h2osno[c], mu_not, flx_slrd_lcl, flx_slri_lcl,
+                                                         V(albsoi, 2), g_star, omega_star, tau_star, albout_lcl,
+                                                         flx_abs_lcl);
+        ELM::snow_snicar::snow_albedo_radiation_factor(urbpoi, flg_slr_in, snl_top, S->coszen[c], mu_not, S->h2osno[c],
+                                                       snw_rds_lcl, V(albsoi, 2), albout_lcl, flx_abs_lcl, albout,
+                                                       flx_abs);
+      }
+    } catch (const std::exception&) {
+      S->err_flags[c] |= REF_THREW;
+    }
+  }
+#undef T1
+#undef TM
+#undef TB
+}
+
+// The soil-moisture-stress block of canopy_fluxes::initialize_flux (canopy_fluxes_impl.hh:131-139):
+// btran starts at btran0 = 0; writes S.eff_porosity, S.rootr, S.btran for every column.
+void elmref_soil_moist_stress(elmo_state* S)
+{
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const elmo_pft_psn* psn = &S->pft_psn[S->vtype[c]];
+    S->btran[c] = 0.0;
+    ELM::soil_moist_stress::calc_effective_soilporosity(V(watsat, 15), V(h2osoi_ice, 20), V(dz, 20),
+                                                        V(eff_porosity, 15));
+    double h2osoi_liqvol[20];
+    ELM::soil_moist_stress::calc_volumetric_h2oliq(V(eff_porosity, 15), V(h2osoi_liq, 20), V(dz, 20), h2osoi_liqvol);
+    ELM::soil_moist_stress::calc_root_moist_stress(h2osoi_liqvol, V(rootfr, 15), V(t_soisno, 20), psn->tc_stress,
+                                                   V(sucsat, 15), V(watsat, 15), V(bsw, 15), psn->smpso, psn->smpsc,
+                                                   V(eff_porosity, 15), S->altmax_indx[c], S->altmax_lastyear_indx[c],
+                                                   V(rootr, 15), S->btran[c]);
+  }
+}
+
+// element-wise probes of the scalar helpers used inside canopy_fluxes
+void elmref_qsat(int64_t n, const double* T, const double* p, double* es, double* esdT, double* qs, double* qsdT)
+{
+  for (int64_t i = 0; i < n; i++) ELM::qsat(T[i], p[i], es[i], esdT[i], qs[i], qsdT[i]);
+}
+
+void elmref_forc_derived(int64_t n, const double* pbot, const double* qbot, const double* tbot, double* rho,
+                         double* po2, double* pco2)
+{
+  for (int64_t i = 0; i < n; i++) {
+    rho[i] = ELM::atm_forcing_physics::derive_forc_rho(pbot[i], qbot[i], tbot[i]);
+    po2[i] = ELM::atm_forcing_physics::derive_forc_po2(pbot[i]);
+    pco2[i] = ELM::atm_forcing_physics::derive_forc_pco2(pbot[i]);
+  }
+}
+
+// out[i*7 + k]: um, obu (monin_obukhov_length), ustar, temp1, temp2, temp12m, temp22m - the call sequence at the
+// head of each canopy_fluxes / bareground_fluxes stability iteration
+void elmref_friction(int64_t n, const double* ur, const double* thv, const double* dthv, const double* zldis,
+                     const double* z0m, const double* z0h, const double* z0q, const double* hgt_u,
+                     const double* hgt_t, const double* hgt_q, const double* displa, double* out)
+{
+  for (int64_t i = 0; i < n; i++) {
+    double um, obu, ustar, temp1, temp2, temp12m, temp22m;
+    ELM::friction_velocity::monin_obukhov_length(ur[i], thv[i], dthv[i], zldis[i], z0m[i], um, obu);
+    ELM::friction_velocity::friction_velocity_wind(hgt_u[i], displa[i], um, obu, z0m[i], ustar);
+    ELM::friction_velocity::friction_velocity_temp(hgt_t[i], displa[i], obu, z0h[i], temp1);
+    ELM::friction_velocity::friction_velocity_humidity(hgt_q[i], hgt_t[i], displa[i], obu, z0h[i], z0q[i], temp1,
+                                                       temp2);
+    ELM::friction_velocity::friction_velocity_temp2m(obu, z0h[i], temp12m);
+    ELM::friction_velocity::friction_velocity_humidity2m(obu, z0h[i], z0q[i], temp12m, temp22m);
+    double* o = out + i * 7;
+    o[0] = um;
+    o[1] = obu;
+    o[2] = ustar;
+    o[3] = temp1;
+    o[4] = temp2;
+    o[5] = temp12m;
+    o[6] = temp22m;
+  }
+}
+
+} // extern "C"

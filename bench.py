@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py - gridcell-timesteps/sec of the full water+energy timestep (all 7 kernels) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cols C] [--tier A|B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  Columns shard halo-free across ranks (elmkernels_amd.decomp: the reference's 1-D block
+split); there is no data-path collective - torch.distributed (RCCL) only carries the barrier and the
+max-over-ranks of the timed region.  Per-GPU work is fixed (weak scaling): --cols columns on every rank.
+
+A "step" = one pass of the reference's ELMInterface::advance hot path over the resident state: restore of the
+snapshot fields (t_veg + forcing heights: what the rest of the model does between steps, 64 B/column), then
+frac_wet -> albedo_snicar -> canopy_hydrology -> surface_radiation -> canopy_temperature -> bareground_fluxes
+-> canopy_fluxes, each a hand-written HIP kernel over SoA state in HBM.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event
+timed on the launch stream) and `cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per column-step (SURVEY.md section 8(d) / BASELINE.md section 3; DESIGN.md restates the tally)
+ALGO_BYTES = {
+    "frac_wet": 44, "albedo_snicar": 960, "canopy_hydrology": 440, "surface_radiation": 640,
+    "canopy_temperature": 753, "bareground_fluxes": 368, "canopy_fluxes": 2076,
+}
+ALGO_BYTES_STEP = sum(ALGO_BYTES.values())  # 5281
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+RESTORE_FIELDS = ["t_veg", "forc_hgt_u_patch", "forc_hgt_t_patch", "forc_hgt_q_patch"]
+NBASE = 47 * 64 * 8  # host-generated base block; the device tiles it to --cols
+
+
+def build_state(ncols, device, tier, seed):
+    from elmkernels_amd import state as st
+    from elmkernels_amd import synth
+
+    ft = st.field_table()
+    nbase = min(NBASE, ncols)
+    cols, scal, soil = synth.make_state(ft, nbase, tier=tier, seed=seed)
+    D = st.ELMState(ncols, device)
+    pft, optics = synth.load_params()
+    D.set_pft(pft)
+    D.set_snicar(optics)
+    D.set_soilcolor(soil["albsat"], soil["albdry"])
+    D.set_land(**synth.TEST_LAND)
+    D.set_scalars(**scal)
+    for k, v in cols.items():
+        D.upload(k, v, col0=0)
+    if ncols > nbase:
+        D.tile_columns(nbase, seed=seed, rules=synth.TILE_RULES)
+    D.snapshot_fields(RESTORE_FIELDS)
+    D.sync()
+    return D, (cols, scal, soil)
+
+
+def cpu_baseline(host_state, budget_s=20.0):
+    """The oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP) on the
+    host cores, on a bounded sample of the same workload."""
+    from tests import helpers as H
+
+    cols, scal, soil = host_state
+    from oracle import oracle as O
+
+    threads = O.lib().lib.elmo_get_max_threads()
+    nb = next(iter(cols.values())).shape[0]
+    n = min(nb, 24064)
+    sub = {k: v[:n] for k, v in cols.items()}
+    S = H.oracle_state(sub, scal, soil)
+    tveg = S["t_veg"].copy()
+    hg = {k: S[k].copy() for k in RESTORE_FIELDS[1:]}
+    S.timestep7(1800.0)  # warm-up (thread pool, page faults)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        S["t_veg"][:] = tveg
+        for k, v in hg.items():
+            S[k][:] = v
+        S.timestep7(1800.0)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 200:
+            break
+    return {
+        "value": n * steps / el, "unit": "gridcell-timesteps/s", "cores": int(threads), "kind": "port",
+        "sample": f"{n} columns x {steps} timesteps of the same tier, oracle/libelmoracle.so (gcc -O2 -fopenmp), {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cols", type=int, default=1_000_000, help="columns per GPU (BASELINE config 2: 1M)")
+    ap.add_argument("--tier", default="B", choices=["A", "B"])
+    ap.add_argument("--seed", type=int, default=0x5EEDE1A0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of the per-kernel HIP-event profile")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU path)")
+
+    from elmkernels_amd import decomp
+    from elmkernels_amd import state as st
+
+    # weak scaling: every rank owns args.cols columns; the global problem is the 1-D block split of world*cols
+    ncols_global = args.cols * world
+    start, ncols = decomp.block_range(ncols_global, world, rank)
+    D, host_state = build_state(ncols, local_rank, args.tier, args.seed + rank)
+
+    def sync_all():
+        D.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        D.restore_fields()
+        st.timestep7(D, 1800.0)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time, HIP events recorded on the stream the kernels are launched on
+    D.restore_fields()
+    ms, ms_total = D.profile_timestep7(1800.0, max(1, args.profile_steps))
+    flags, first_bad = D.error_summary()
+
+    if rank == 0:
+        value = ncols_global * args.steps / elapsed
+        kern = {}
+        for name, m in zip(st.KERNEL_NAMES, ms):
+            gbs = ALGO_BYTES[name] * ncols / (m * 1e-3) / 1e9 if m > 0 else 0.0
+            kern[name] = {"ms": round(m, 4), "algo_GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max(zip(st.KERNEL_NAMES, ms), key=lambda x: x[1])
+        dom_gbs = ALGO_BYTES[dom[0]] * ncols / (dom[1] * 1e-3) / 1e9
+        step_gbs = ALGO_BYTES_STEP * ncols / (ms_total * 1e-3) / 1e9
+        out = {
+            "metric": "gridcell-timesteps/sec",
+            "value": value,
+            "unit": "gridcell-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"full water+energy timestep (7 kernels), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
+                "columns_per_gpu": args.cols,
+                "columns_total": ncols_global,
+                "levels": 20,
+                "tier": {"A": "fixture-tiled", "B": "branch-mix"}[args.tier],
+                "parallelism": f"columns block-split over {world} GPU(s), no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_" + dom[0],
+                "achieved": dom_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": dom_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_column": ALGO_BYTES[dom[0]],
+                "avg_launch_ms": dom[1],
+            },
+            "timestep_roofline": {
+                "bytes_per_column_step": ALGO_BYTES_STEP, "achieved_GBps": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                "ms_per_step_events": ms_total,
+            },
+            "kernels": kern,
+            "error_flags": flags,
+            "device_state_GB": round(D.device_bytes / 1e9, 3),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_state)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    D.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,622 @@
+// elmk_api.cpp - host side of the C ABI declared in include/elmk.h.
+//
+// Owns the device arena (every field of elmk_fields.def as SoA [lev][column], level stride padded to 64
+// columns, each field 256-byte aligned), the parameter block (DevState) mirrored into device memory, one
+// HIP stream, and a staging buffer for layout conversion.  No physics lives here and there is no CPU path:
+// every elmk_<physics>() is a single kernel launch on the context's stream.
+#include "elmk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "elmk_dev.h"
+#include "elmk_kernels.h"
+
+using namespace elmk;
+
+namespace {
+
+struct FieldDesc {
+  const char* name;
+  int dtype;
+  int nlev;
+};
+
+const FieldDesc g_fields[ELMK_NUM_FIELDS] = {
+#define ELMK_FIELD(name, T, nlev) {#name, ELMK_##T, nlev},
+#include "elmk_fields.def"
+#undef ELMK_FIELD
+    {"err_flags", ELMK_U32, 1},
+};
+
+inline int elem_size(int dtype) { return dtype == ELMK_F64 ? 8 : (dtype == ELMK_U8 ? 1 : 4); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+thread_local std::string g_create_error;
+constexpr int MAXLEV_STAGE = 21;  // widest field (zisoi)
+
+}  // namespace
+
+struct elmk_ctx {
+  int dev = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int64_t ncols = 0;
+  int64_t ld = 0;
+  DevState h;            // host mirror of the device parameter block
+  DevState* d = nullptr; // device copy handed to kernels
+  bool dirty = true;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  void* fptr[ELMK_NUM_FIELDS] = {};
+  double* snicar = nullptr;
+  char* staging = nullptr;  // device staging for layout conversion
+  size_t staging_bytes = 0;
+  std::vector<int> snap_fields;  // elmk_snapshot_fields
+  std::vector<char*> snap_bufs;
+  uint32_t* red_or = nullptr;  // device scalars for elmk_error_summary
+  long long* red_first = nullptr;
+  std::string err;
+};
+
+namespace {
+
+bool hip_fail(elmk_ctx* ctx, hipError_t e, const char* what)
+{
+  if (e == hipSuccess) return false;
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  if (ctx) ctx->err = buf;
+  g_create_error = buf;
+  return true;
+}
+
+#define HIPCHK(call)                                      \
+  do {                                                    \
+    if (hip_fail(ctx, (call), #call)) return ELMK_E_HIP;  \
+  } while (0)
+
+int invalid(elmk_ctx* ctx, const char* msg)
+{
+  if (ctx) ctx->err = msg;
+  g_create_error = msg;
+  return ELMK_E_INVALID;
+}
+
+int push_params(elmk_ctx* ctx)
+{
+  if (!ctx->dirty) return ELMK_OK;
+  HIPCHK(hipMemcpyAsync(ctx->d, &ctx->h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
+  // the source is pageable host memory: the runtime has staged it before returning, so h may change again
+  ctx->dirty = false;
+  return ELMK_OK;
+}
+
+int enter(elmk_ctx* ctx)
+{
+  if (!ctx) return ELMK_E_INVALID;
+  HIPCHK(hipSetDevice(ctx->dev));
+  return ELMK_OK;
+}
+
+bool field_ok(int f) { return f >= 0 && f < ELMK_NUM_FIELDS; }
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------------
+int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
+{
+  if (!out || ncols < 0) return invalid(nullptr, "elmk_create: bad arguments");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("elmk_create: no HIP device (") + hipGetErrorString(e) +
+                     "); libelmk has no CPU fallback";
+    return ELMK_E_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    g_create_error = "elmk_create: device id out of range";
+    return ELMK_E_NO_DEVICE;
+  }
+  elmk_ctx* ctx = new (std::nothrow) elmk_ctx();
+  if (!ctx) return ELMK_E_NOMEM;
+  ctx->dev = device_id;
+  ctx->ncols = ncols;
+  ctx->ld = (int64_t)align_up((size_t)(ncols > 0 ? ncols : 1), 64);
+
+  auto fail = [&](int code) {
+    elmk_destroy(ctx);
+    return code;
+  };
+  if (hip_fail(ctx, hipSetDevice(device_id), "hipSetDevice")) return fail(ELMK_E_HIP);
+  if (hip_fail(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreate"))
+    return fail(ELMK_E_HIP);
+  ctx->stream = ctx->own_stream;
+
+  // arena layout
+  size_t off = 0;
+  size_t foff[ELMK_NUM_FIELDS];
+  for (int f = 0; f < ELMK_NUM_FIELDS; f++) {
+    foff[f] = off;
+    off += align_up((size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype), 256);
+  }
+  ctx->arena_bytes = off;
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->arena, off), "hipMalloc(state arena)")) return fail(ELMK_E_NOMEM);
+  if (hip_fail(ctx, hipMemsetAsync(ctx->arena, 0, off, ctx->stream), "hipMemset(state arena)")) return fail(ELMK_E_HIP);
+  for (int f = 0; f < ELMK_NUM_FIELDS; f++) ctx->fptr[f] = ctx->arena + foff[f];
+
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->snicar, SN_TOTAL * sizeof(double)), "hipMalloc(snicar)"))
+    return fail(ELMK_E_NOMEM);
+  if (hip_fail(ctx, hipMemsetAsync(ctx->snicar, 0, SN_TOTAL * sizeof(double), ctx->stream), "hipMemset(snicar)"))
+    return fail(ELMK_E_HIP);
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->red_or, 16), "hipMalloc(reduce)")) return fail(ELMK_E_NOMEM);
+  ctx->red_first = (long long*)((char*)ctx->red_or + 8);
+
+  // staging: up to 32 MiB, at least one 64-column tile of the widest field
+  size_t want = (size_t)MAXLEV_STAGE * 8 * (size_t)(ncols > 0 ? ncols : 1);
+  if (want > ((size_t)32 << 20)) want = (size_t)32 << 20;
+  if (want < (size_t)MAXLEV_STAGE * 8 * 64) want = (size_t)MAXLEV_STAGE * 8 * 64;
+  ctx->staging_bytes = want;
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->staging, want), "hipMalloc(staging)")) return fail(ELMK_E_NOMEM);
+
+  // parameter block defaults: LandType() (land_data.h:38) and ELMState scalars (elm_state.h:221-224)
+  DevState& h = ctx->h;
+  memset(&h, 0, sizeof h);
+  h.ncols = ncols;
+  h.ld = ctx->ld;
+  h.land = Land{1, 0, 2, 0, 0};
+  h.dewmx = 0.1;
+  h.oldfflag = 1;
+  h.snicar = ctx->snicar;
+  {
+    int f = 0;
+#define ELMK_FIELD(name, T, nlev) h.name = (ctype_of<ELMK_##T>::type*)ctx->fptr[f++];
+#include "elmk_fields.def"
+#undef ELMK_FIELD
+    h.err_flags = (uint32_t*)ctx->fptr[f];
+  }
+  ctx->dirty = true;
+  if (hip_fail(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return fail(ELMK_E_HIP);
+  *out = ctx;
+  return ELMK_OK;
+}
+
+int elmk_destroy(elmk_ctx* ctx)
+{
+  if (!ctx) return ELMK_OK;
+  (void)hipSetDevice(ctx->dev);
+  if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->snicar) (void)hipFree(ctx->snicar);
+  if (ctx->d) (void)hipFree(ctx->d);
+  if (ctx->red_or) (void)hipFree(ctx->red_or);
+  if (ctx->staging) (void)hipFree(ctx->staging);
+  for (char* b : ctx->snap_bufs) (void)hipFree(b);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return ELMK_OK;
+}
+
+const char* elmk_last_error(const elmk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int elmk_set_stream(elmk_ctx* ctx, void* hip_stream)
+{
+  if (int rc = enter(ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return ELMK_OK;
+}
+
+int elmk_sync(elmk_ctx* ctx)
+{
+  if (int rc = enter(ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ELMK_OK;
+}
+
+int64_t elmk_ncols(const elmk_ctx* ctx) { return ctx ? ctx->ncols : -1; }
+int64_t elmk_level_stride(const elmk_ctx* ctx) { return ctx ? ctx->ld : -1; }
+int64_t elmk_device_bytes(const elmk_ctx* ctx)
+{
+  return ctx ? (int64_t)(ctx->arena_bytes + ctx->staging_bytes + SN_TOTAL * sizeof(double) + sizeof(DevState)) : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// schema
+// ---------------------------------------------------------------------------------------------------
+int elmk_num_fields(void) { return ELMK_NUM_FIELDS; }
+const char* elmk_field_name(int field) { return field_ok(field) ? g_fields[field].name : nullptr; }
+int elmk_field_id(const char* name)
+{
+  if (!name) return -1;
+  for (int f = 0; f < ELMK_NUM_FIELDS; f++)
+    if (strcmp(name, g_fields[f].name) == 0) return f;
+  return -1;
+}
+int elmk_field_info(int field, int* nlev, int* dtype)
+{
+  if (!field_ok(field)) return ELMK_E_INVALID;
+  if (nlev) *nlev = g_fields[field].nlev;
+  if (dtype) *dtype = g_fields[field].dtype;
+  return ELMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// data movement
+// ---------------------------------------------------------------------------------------------------
+static int xfer(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout, bool up)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (!field_ok(field) || (!host && n > 0) || col0 < 0 || n < 0 || col0 + n > ctx->ncols)
+    return invalid(ctx, "elmk_upload/download: bad field or column range");
+  if (n == 0) return ELMK_OK;
+  const int es = elem_size(g_fields[field].dtype), nlev = g_fields[field].nlev;
+  char* dev = (char*)ctx->fptr[field];
+  if (layout == ELMK_LAYOUT_SOA || nlev == 1) {
+    // rows of n elements <-> rows of ld elements
+    if (up)
+      HIPCHK(hipMemcpy2DAsync(dev + (size_t)col0 * es, (size_t)ctx->ld * es, host, (size_t)n * es, (size_t)n * es, nlev,
+                              hipMemcpyHostToDevice, ctx->stream));
+    else
+      HIPCHK(hipMemcpy2DAsync(host, (size_t)n * es, dev + (size_t)col0 * es, (size_t)ctx->ld * es, (size_t)n * es, nlev,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ELMK_OK;
+  }
+  if (layout != ELMK_LAYOUT_COL_MAJOR) return invalid(ctx, "elmk_upload/download: unknown layout");
+  // reference layout [col][lev]: go through the device staging buffer in chunks of whole 64-column tiles
+  int64_t chunk = (int64_t)(ctx->staging_bytes / ((size_t)nlev * es));
+  chunk = chunk / 64 * 64;
+  if (chunk <= 0) return invalid(ctx, "staging buffer too small");
+  for (int64_t done = 0; done < n; done += chunk) {
+    const int64_t m = (n - done) < chunk ? (n - done) : chunk;
+    char* hp = (char*)host + (size_t)done * nlev * es;
+    if (up) {
+      HIPCHK(hipMemcpyAsync(ctx->staging, hp, (size_t)m * nlev * es, hipMemcpyHostToDevice, ctx->stream));
+      launch_cols_to_soa(ctx->staging, dev, es, nlev, ctx->ld, col0 + done, m, ctx->stream);
+    } else {
+      launch_soa_to_cols(dev, ctx->staging, es, nlev, ctx->ld, col0 + done, m, ctx->stream);
+      HIPCHK(hipMemcpyAsync(hp, ctx->staging, (size_t)m * nlev * es, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // staging is reused by the next chunk
+  }
+  return ELMK_OK;
+}
+
+int elmk_upload(elmk_ctx* ctx, int field, const void* host, int64_t col0, int64_t n, int layout)
+{
+  return xfer(ctx, field, const_cast<void*>(host), col0, n, layout, true);
+}
+int elmk_download(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout)
+{
+  return xfer(ctx, field, host, col0, n, layout, false);
+}
+
+int elmk_fill(elmk_ctx* ctx, int field, double value)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (!field_ok(field)) return invalid(ctx, "elmk_fill: bad field");
+  launch_fill(ctx->fptr[field], g_fields[field].dtype, g_fields[field].nlev, ctx->ld, ctx->ncols, value, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+void* elmk_device_ptr(elmk_ctx* ctx, int field) { return (ctx && field_ok(field)) ? ctx->fptr[field] : nullptr; }
+
+int elmk_tile_columns(elmk_ctx* ctx, int64_t nbase, uint64_t seed, int nrules, const elmk_perturb* rules)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (nbase <= 0 || nbase > ctx->ncols || nrules < 0 || (nrules > 0 && !rules))
+    return invalid(ctx, "elmk_tile_columns: bad arguments");
+  for (int f = 0; f < ELMK_NUM_FIELDS; f++) {
+    int mode = -1;
+    double amp = 0.0;
+    for (int r = 0; r < nrules; r++) {
+      if (rules[r].field == f) {
+        mode = rules[r].mode;
+        amp = rules[r].amp;
+      }
+    }
+    launch_tile(ctx->fptr[f], g_fields[f].dtype, g_fields[f].nlev, ctx->ld, ctx->ncols, nbase, seed, f, mode, amp,
+                ctx->stream);
+  }
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_snapshot_fields(elmk_ctx* ctx, const int* fields, int nfields)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (nfields < 0 || (nfields > 0 && !fields)) return invalid(ctx, "elmk_snapshot_fields: bad arguments");
+  for (int i = 0; i < nfields; i++)
+    if (!field_ok(fields[i])) return invalid(ctx, "elmk_snapshot_fields: unknown field");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (char* b : ctx->snap_bufs) (void)hipFree(b);
+  ctx->snap_bufs.clear();
+  ctx->snap_fields.clear();
+  for (int i = 0; i < nfields; i++) {
+    const int f = fields[i];
+    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype);
+    char* b = nullptr;
+    HIPCHK(hipMalloc((void**)&b, bytes));
+    ctx->snap_bufs.push_back(b);
+    ctx->snap_fields.push_back(f);
+    HIPCHK(hipMemcpyAsync(b, ctx->fptr[f], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ELMK_OK;
+}
+
+int elmk_restore_fields(elmk_ctx* ctx)
+{
+  if (int rc = enter(ctx)) return rc;
+  for (size_t i = 0; i < ctx->snap_fields.size(); i++) {
+    const int f = ctx->snap_fields[i];
+    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype);
+    HIPCHK(hipMemcpyAsync(ctx->fptr[f], ctx->snap_bufs[i], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return ELMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------------
+int elmk_set_land(elmk_ctx* ctx, int ltype, int ctype, int vtype, int urbpoi, int lakpoi)
+{
+  if (!ctx) return ELMK_E_INVALID;
+  if (vtype < 0 || vtype >= ELMK_MXPFT) return invalid(ctx, "elmk_set_land: vtype out of range");
+  ctx->h.land = Land{ltype, ctype, vtype, urbpoi != 0, lakpoi != 0};
+  ctx->dirty = true;
+  return ELMK_OK;
+}
+
+int elmk_set_scalars(elmk_ctx* ctx, double dewmx, int oldfflag, double dayl, double max_dayl)
+{
+  if (!ctx) return ELMK_E_INVALID;
+  ctx->h.dewmx = dewmx;
+  ctx->h.oldfflag = oldfflag;
+  ctx->h.dayl = dayl;
+  ctx->h.max_dayl = max_dayl;
+  ctx->dirty = true;
+  return ELMK_OK;
+}
+
+int elmk_set_pft(elmk_ctx* ctx, const double* psn, const double* alb, const double* z0mr, const double* displar)
+{
+  if (!ctx || !psn || !alb || !z0mr || !displar) return invalid(ctx, "elmk_set_pft: null table");
+  memcpy(ctx->h.pft_psn, psn, sizeof ctx->h.pft_psn);
+  memcpy(ctx->h.pft_alb, alb, sizeof ctx->h.pft_alb);
+  memcpy(ctx->h.z0mr, z0mr, sizeof ctx->h.z0mr);
+  memcpy(ctx->h.displar, displar, sizeof ctx->h.displar);
+  ctx->dirty = true;
+  return ELMK_OK;
+}
+
+int elmk_set_soilcolor(elmk_ctx* ctx, const double* albsat, const double* albdry)
+{
+  if (!ctx || !albsat || !albdry) return invalid(ctx, "elmk_set_soilcolor: null table");
+  memcpy(ctx->h.albsat, albsat, sizeof ctx->h.albsat);
+  memcpy(ctx->h.albdry, albdry, sizeof ctx->h.albdry);
+  ctx->dirty = true;
+  return ELMK_OK;
+}
+
+int elmk_set_snicar(elmk_ctx* ctx, const elmk_snicar_tables* t)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (!t) return invalid(ctx, "elmk_set_snicar: null");
+  std::vector<double> buf(SN_TOTAL, 0.0);
+  const double* aer[6][3] = {
+      {t->ss_alb_oc1, t->asm_prm_oc1, t->ext_cff_mss_oc1},    {t->ss_alb_oc2, t->asm_prm_oc2, t->ext_cff_mss_oc2},
+      {t->ss_alb_dst1, t->asm_prm_dst1, t->ext_cff_mss_dst1}, {t->ss_alb_dst2, t->asm_prm_dst2, t->ext_cff_mss_dst2},
+      {t->ss_alb_dst3, t->asm_prm_dst3, t->ext_cff_mss_dst3}, {t->ss_alb_dst4, t->asm_prm_dst4, t->ext_cff_mss_dst4}};
+  for (int s = 0; s < 6; s++)
+    for (int p = 0; p < 3; p++) {
+      if (!aer[s][p]) return invalid(ctx, "elmk_set_snicar: null aerosol table");
+      memcpy(&buf[SN_OC1 + s * SN_AER_STRIDE + p * 5], aer[s][p], 5 * sizeof(double));
+    }
+  const double* snw[2][3] = {{t->ss_alb_snw_drc, t->asm_prm_snw_drc, t->ext_cff_mss_snw_drc},
+                             {t->ss_alb_snw_dfs, t->asm_prm_snw_dfs, t->ext_cff_mss_snw_dfs}};
+  for (int k = 0; k < 2; k++)
+    for (int p = 0; p < 3; p++) {
+      if (!snw[k][p]) return invalid(ctx, "elmk_set_snicar: null Mie table");
+      memcpy(&buf[(k == 0 ? SN_SNW_DRC : SN_SNW_DFS) + p * 5 * ELMK_MIE_N], snw[k][p], 5 * ELMK_MIE_N * sizeof(double));
+    }
+  const double* bc[2][3] = {{t->ss_alb_bc1, t->asm_prm_bc1, t->ext_cff_mss_bc1},
+                            {t->ss_alb_bc2, t->asm_prm_bc2, t->ext_cff_mss_bc2}};
+  for (int k = 0; k < 2; k++)
+    for (int p = 0; p < 3; p++) {
+      if (!bc[k][p]) return invalid(ctx, "elmk_set_snicar: null BC table");
+      memcpy(&buf[(k == 0 ? SN_BC1 : SN_BC2) + p * 50], bc[k][p], 50 * sizeof(double));
+    }
+  if (!t->bcenh) return invalid(ctx, "elmk_set_snicar: null bcenh");
+  memcpy(&buf[SN_BCENH], t->bcenh, 400 * sizeof(double));
+  HIPCHK(hipMemcpyAsync(ctx->snicar, buf.data(), SN_TOTAL * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ELMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// physics wrappers: one launch each, same order/arguments as driver/kokkos
+// ---------------------------------------------------------------------------------------------------
+#define PHYSICS_PROLOGUE()                 \
+  if (int rc = enter(ctx)) return rc;      \
+  if (int rc = push_params(ctx)) return rc
+
+int elmk_frac_wet(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_albedo_snicar(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_canopy_hydrology(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_surface_radiation(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_canopy_temperature(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_bareground_fluxes(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+int elmk_canopy_fluxes(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+// ELMInterface::advance order (elm_kokkos_interface.cc:289-307)
+int elmk_timestep7(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
+  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+  launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
+  launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
+  launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
+  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------------------------------
+int elmk_error_summary(elmk_ctx* ctx, uint32_t* or_of_flags, int64_t* first_bad_col)
+{
+  if (int rc = enter(ctx)) return rc;
+  const long long none = 0x7fffffffffffffffll;
+  HIPCHK(hipMemsetAsync(ctx->red_or, 0, 8, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->red_first, &none, 8, hipMemcpyHostToDevice, ctx->stream));
+  launch_flag_reduce((const uint32_t*)ctx->fptr[ELMK_FIELD_err_flags], ctx->ncols, ctx->red_or, ctx->red_first,
+                     ctx->stream);
+  HIPCHK(hipGetLastError());
+  uint32_t o = 0;
+  long long first = none;
+  HIPCHK(hipMemcpyAsync(&o, ctx->red_or, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&first, ctx->red_first, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (or_of_flags) *or_of_flags = o;
+  if (first_bad_col) *first_bad_col = (first == none) ? -1 : (int64_t)first;
+  return ELMK_OK;
+}
+
+int elmk_clear_errors(elmk_ctx* ctx) { return elmk_fill(ctx, ELMK_FIELD_err_flags, 0.0); }
+
+int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_kernel, float* ms_total)
+{
+  PHYSICS_PROLOGUE();
+  if (nsteps <= 0) return invalid(ctx, "elmk_profile_timestep7: nsteps <= 0");
+  std::vector<hipEvent_t> ev((size_t)nsteps * 8);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  for (int s = 0; s < nsteps; s++) {
+    hipEvent_t* e = &ev[(size_t)s * 8];
+    HIPCHK(hipEventRecord(e[0], ctx->stream));
+    launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
+    HIPCHK(hipEventRecord(e[1], ctx->stream));
+    launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+    HIPCHK(hipEventRecord(e[2], ctx->stream));
+    launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
+    HIPCHK(hipEventRecord(e[3], ctx->stream));
+    launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
+    HIPCHK(hipEventRecord(e[4], ctx->stream));
+    launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
+    HIPCHK(hipEventRecord(e[5], ctx->stream));
+    launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
+    HIPCHK(hipEventRecord(e[6], ctx->stream));
+    launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+    HIPCHK(hipEventRecord(e[7], ctx->stream));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0}, tot = 0.0;
+  for (int s = 0; s < nsteps; s++) {
+    hipEvent_t* e = &ev[(size_t)s * 8];
+    for (int k = 0; k < 7; k++) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e[k], e[k + 1]));
+      acc[k] += ms;
+    }
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e[0], e[7]));
+    tot += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (ms_per_kernel)
+    for (int k = 0; k < 7; k++) ms_per_kernel[k] = (float)(acc[k] / nsteps);
+  if (ms_total) *ms_total = (float)(tot / nsteps);
+  return ELMK_OK;
+}
+
+int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_per_s)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (bytes < 8 || iters <= 0 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
+  const int64_t n = bytes / 8;
+  double *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void**)&a, (size_t)n * 8));
+  if (hip_fail(ctx, hipMalloc((void**)&b, (size_t)n * 8), "hipMalloc")) {
+    (void)hipFree(a);
+    return ELMK_E_NOMEM;
+  }
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemsetAsync(a, 0, (size_t)n * 8, ctx->stream));
+  launch_copy(a, b, n, ctx->stream);  // warm-up
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < iters; i++) launch_copy(a, b, n, ctx->stream);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *gbytes_per_s = 2.0 * (double)n * 8.0 * iters / ((double)ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  return ELMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// elmk_dev.h - device-side view of the column state and the small scalar helpers every kernel uses.
+//
+// Layout in HBM (DESIGN.md "Data layout"): every field is SoA [lev][column], column fastest; the level
+// stride `ld` is ncols rounded up to 64 so each level row starts on a 512-byte boundary.  A wave64 that
+// reads one level of one field therefore issues one fully coalesced 512-byte (fp64) request.
+// One thread owns one column; kernels read each touched element once and write each result once.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "elmk.h"
+
+namespace elmk {
+
+// ---- physical constants: values of src/data/elm_constants.h:18-53, formed by the same expressions ----
+constexpr double TFRZ = 273.15;
+constexpr double ELM_PI = 3.14159265358979323846;
+constexpr double BOLTZ = 1.38065e-23;
+constexpr double AVOGAD = 6.02214e26;
+constexpr double MWWV = 18.016;
+constexpr double RGAS = AVOGAD * BOLTZ;
+constexpr double RWV = RGAS / MWWV;
+constexpr double STEBOL = 5.67e-8;
+constexpr double MWDAIR = 28.966;
+constexpr double RAIR = RGAS / MWDAIR;
+constexpr double GRAV = 9.80616;
+constexpr double ROVERG = RWV / GRAV * 1000.;
+constexpr double O2_MOLAR_CONST = 0.209;
+constexpr double CO2_PPMV = 355.0;
+constexpr double DENICE = 0.917e3;
+constexpr double DENH2O = 1.000e3;
+constexpr double HVAP = 2.501e6;
+constexpr double HFUS = 3.337e5;
+constexpr double HSUB = HVAP + HFUS;
+constexpr double VKC = 0.4;
+constexpr double CPAIR = 1.00464e3;
+constexpr double CSOILC = 0.004;
+constexpr double ZLND = 0.01;
+constexpr double ZSNO = 0.0024;
+constexpr double SNW_RDS_MIN = 54.526;
+constexpr double SPVAL = 1.0e36;
+
+// land-unit / column codes: src/data/land_data.h:8-31
+enum : int {
+  istsoil = 1,
+  istcrop = 2,
+  istice = 3,
+  istice_mec = 4,
+  istdlak = 5,
+  istwet = 6,
+  icol_roof = 71,
+  icol_sunwall = 72,
+  icol_shadewall = 73,
+  icol_road_imperv = 74,
+  icol_road_perv = 75,
+  pft_nsoybean = 23,
+  pft_nsoybeanirrig = 24
+};
+
+constexpr int NLEVSNO = ELMK_NLEVSNO;
+constexpr int NLEVGRND = ELMK_NLEVGRND;
+constexpr int NLEVTOT = ELMK_NLEVTOT;
+
+template <int T> struct ctype_of;
+template <> struct ctype_of<ELMK_F64> { using type = double; };
+template <> struct ctype_of<ELMK_I32> { using type = int32_t; };
+template <> struct ctype_of<ELMK_U8> { using type = uint8_t; };
+
+// indices into one row of the PFT photosynthesis table (member order of ELM::PFTDataPSN, pft_data.h:20-24)
+enum : int {
+  P_fnr, P_act25, P_kcha, P_koha, P_cpha, P_vcmaxha, P_jmaxha, P_tpuha, P_lmrha, P_vcmaxhd, P_jmaxhd, P_tpuhd,
+  P_lmrhd, P_lmrse, P_qe, P_theta_cj, P_bbbopt, P_mbbopt, P_c3psn, P_slatop, P_leafcn, P_flnr, P_fnitr, P_dleaf,
+  P_smpso, P_smpsc, P_tc_stress
+};
+
+struct Land {
+  int ltype, ctype, vtype, urbpoi, lakpoi;
+};
+
+// SNICAR tables on the device (one contiguous buffer; offsets in doubles)
+struct SnicarDev {
+  const double* base;
+};
+enum : int {
+  SN_OC1 = 0,                      // ss_alb, asm_prm, ext_cff_mss: 3 x [5] each for oc1, oc2, dst1..4
+  SN_AER_STRIDE = 15,              // per species block
+  SN_SNW_DRC = 6 * 15,             // 3 x [5][1471]
+  SN_SNW_DFS = SN_SNW_DRC + 3 * 5 * ELMK_MIE_N,
+  SN_BC1 = SN_SNW_DFS + 3 * 5 * ELMK_MIE_N,  // 3 x [10][5]
+  SN_BC2 = SN_BC1 + 150,
+  SN_BCENH = SN_BC2 + 150,         // [8][10][5]
+  SN_TOTAL = SN_BCENH + 400
+};
+
+// Everything a kernel needs, resident in device memory (kernels get one pointer; all loads from this
+// struct are wave-uniform and become scalar loads).
+struct DevState {
+  int64_t ncols;
+  int64_t ld;  // level stride (elements)
+  Land land;
+  double dewmx;
+  int oldfflag;
+  double dayl, max_dayl;
+  double pft_psn[ELMK_MXPFT][ELMK_PSN_NPARAM];
+  double pft_alb[ELMK_MXPFT][ELMK_ALB_NPARAM];
+  double z0mr[ELMK_MXPFT], displar[ELMK_MXPFT];
+  double albsat[ELMK_NSOILCOL][2], albdry[ELMK_NSOILCOL][2];
+  const double* snicar;  // SN_TOTAL doubles
+#define ELMK_FIELD(name, T, nlev) ctype_of<ELMK_##T>::type* name;
+#include "elmk_fields.def"
+#undef ELMK_FIELD
+  uint32_t* err_flags;
+};
+
+// std::min / std::max of the reference (<algorithm>): first argument wins ties and NaNs
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
+
+// ---- src/physics/qsat_impl.hh:7-78 ------------------------------------------------------------------
+__device__ __forceinline__ void qsat(double T, double p, double& es, double& esdT, double& qs, double& qsdT)
+{
+  double td = T - TFRZ;
+  if (td > 100.0) td = 100.0;
+  if (td < -75.0) td = -75.0;
+  if (td >= 0.0) {
+    es = 6.11213476 +
+         td * (0.444007856 +
+               td * (0.143064234e-01 +
+                     td * (0.264461437e-03 +
+                           td * (0.305903558e-05 +
+                                 td * (0.196237241e-07 + td * (0.892344772e-10 + td * (-0.373208410e-12 + td * 0.209339997e-15)))))));
+    esdT = 0.444017302 +
+           td * (0.286064092e-01 +
+                 td * (0.794683137e-03 +
+                       td * (0.121211669e-04 +
+                             td * (0.103354611e-06 +
+                                   td * (0.404125005e-09 + td * (-0.788037859e-12 + td * (-0.114596802e-13 + td * 0.381294516e-16)))))));
+  } else {
+    es = 6.11123516 +
+         td * (0.503109514 +
+               td * (0.188369801e-01 +
+                     td * (0.420547422e-03 +
+                           td * (0.614396778e-05 +
+                                 td * (0.602780717e-07 + td * (0.387940929e-09 + td * (0.149436277e-11 + td * 0.262655803e-14)))))));
+    esdT = 0.503277922 +
+           td * (0.377289173e-01 +
+                 td * (0.126801703e-02 +
+                       td * (0.249468427e-04 +
+                             td * (0.313703411e-06 +
+                                   td * (0.257180651e-08 + td * (0.133268878e-10 + td * (0.394116744e-13 + td * 0.498070196e-16)))))));
+  }
+  es = es * 100.0;
+  esdT = esdT * 100.0;
+  const double vp = 1.0 / (p - 0.378 * es);
+  const double vp1 = 0.622 * vp;
+  const double vp2 = vp1 * vp;
+  qs = es * vp1;
+  qsdT = esdT * vp2 * p;
+}
+
+// ---- src/physics/atm_physics_impl.hh:246-272 --------------------------------------------------------
+__device__ __forceinline__ double derive_forc_vp(double qbot, double pbot) { return qbot * pbot / (0.622 + 0.378 * qbot); }
+__device__ __forceinline__ double derive_forc_rho(double pbot, double qbot, double tbot)
+{
+  return (pbot - 0.378 * derive_forc_vp(qbot, pbot)) / (RAIR * tbot);
+}
+__device__ __forceinline__ double derive_forc_po2(double pbot) { return O2_MOLAR_CONST * pbot; }
+__device__ __forceinline__ double derive_forc_pco2(double pbot) { return CO2_PPMV * 1.0e-6 * pbot; }
+
+// ---- src/physics/friction_velocity_impl.hh ----------------------------------------------------------
+// :17-24, :27-33
+__device__ __forceinline__ double stab1(double zeta)
+{
+  const double chik2 = sqrt(1.0 - 16.0 * zeta);
+  const double chik = sqrt(chik2);
+  return 2.0 * log((1.0 + chik) * 0.5) + log((1.0 + chik2) * 0.5) - 2.0 * atan(chik) + ELM_PI * 0.5;
+}
+__device__ __forceinline__ double stab2(double zeta)
+{
+  const double chik2 = sqrt(1.0 - 16.0 * zeta);
+  return 2.0 * log((1.0 + chik2) * 0.5);
+}
+
+// :36-61
+__device__ __forceinline__ void monin_obukhov_length(double ur, double thv, double dthv, double zldis, double z0m,
+                                                     double& um, double& obu)
+{
+  const double wc = 0.5;
+  if (dthv >= 0.0) {
+    um = dmax(ur, 0.1);
+  } else {
+    um = sqrt(ur * ur + wc * wc);
+  }
+  const double rib = GRAV * zldis * dthv / (thv * um * um);
+  double zeta;
+  if (rib >= 0.0) {
+    zeta = rib * log(zldis / z0m) / (1.0 - 5.0 * dmin(rib, 0.19));
+    zeta = dmin(2.0, dmax(zeta, 0.01));
+  } else {
+    zeta = rib * log(zldis / z0m);
+    zeta = dmax(-100.0, dmin(zeta, -0.01));
+  }
+  obu = zldis / zeta;
+}
+
+// :64-83
+__device__ __forceinline__ double fv_wind(double forc_hgt_u, double displa, double um, double obu, double z0m)
+{
+  const double zetam = 1.574;
+  const double zldis = forc_hgt_u - displa;
+  const double zeta = zldis / obu;
+  if (zeta < (-zetam)) {
+    return VKC * um /
+           (log(-zetam * obu / z0m) - stab1(-zetam) + stab1(z0m / obu) + 1.14 * (pow((-zeta), 0.333) - pow(zetam, 0.333)));
+  } else if (zeta < 0.0) {
+    return VKC * um / (log(zldis / z0m) - stab1(zeta) + stab1(z0m / obu));
+  } else if (zeta <= 1.0) {
+    return VKC * um / (log(zldis / z0m) + 5.0 * zeta - 5.0 * z0m / obu);
+  }
+  return VKC * um / (log(obu / z0m) + 5.0 - 5.0 * z0m / obu + (5.0 * log(zeta) + zeta - 1.0));
+}
+
+// the temperature/humidity profile relation shared by :86-172 (zetat = 0.465); GROUPED selects the
+// "5.0 * (z0h / obu)" grouping that only friction_velocity_temp2m's last branch has (:148)
+template <bool GROUPED>
+__device__ __forceinline__ double fv_profile(double zldis, double obu, double z0)
+{
+  const double zetat = 0.465;
+  const double zeta = zldis / obu;
+  if (zeta < -zetat) {
+    return VKC / (log(-zetat * obu / z0) - stab2(-zetat) + stab2(z0 / obu) + 0.8 * (pow(zetat, -0.333) - pow((-zeta), -0.333)));
+  } else if (zeta < 0.0) {
+    return VKC / (log(zldis / z0) - stab2(zeta) + stab2(z0 / obu));
+  } else if (zeta <= 1.0) {
+    return VKC / (log(zldis / z0) + 5.0 * zeta - 5.0 * z0 / obu);
+  }
+  if (GROUPED) return VKC / (log(obu / z0) + 5.0 - 5.0 * (z0 / obu) + (5.0 * log(zeta) + zeta - 1.0));
+  return VKC / (log(obu / z0) + 5.0 - 5.0 * z0 / obu + (5.0 * log(zeta) + zeta - 1.0));
+}
+
+// the five calls that open every stability iteration (bareground_fluxes_impl.hh:52-57, canopy_fluxes_impl.hh:235-240)
+__device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
+                                                  double obu, double z0m, double z0h, double z0q, double& ustar,
+                                                  double& temp1, double& temp2, double& temp12m, double& temp22m)
+{
+  ustar = fv_wind(hgt_u, displa, um, obu, z0m);
+  temp1 = fv_profile<false>(hgt_t - displa, obu, z0h);                     // friction_velocity_temp :86
+  if (hgt_q == hgt_t && z0q == z0h) {                                      // friction_velocity_humidity :107
+    temp2 = temp1;
+  } else {
+    temp2 = fv_profile<false>(hgt_q - displa, obu, z0q);
+  }
+  temp12m = fv_profile<true>(2.0 + z0h, obu, z0h);                         // friction_velocity_temp2m :134
+  if (z0q == z0h) {                                                        // friction_velocity_humidity2m :153
+    temp22m = temp12m;
+  } else {
+    temp22m = fv_profile<false>(2.0 + z0q, obu, z0q);
+  }
+}
+
+}  // namespace elmk

@@ -1,0 +1,34 @@
+// elmk_kernels.h - host-callable launchers of the HIP kernels (defined in the k_*.hip files)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "elmk.h"
+
+namespace elmk {
+
+struct DevState;
+
+// the seven physics launches (one per reference L3 wrapper)
+void launch_frac_wet(const DevState* S, int64_t n, hipStream_t st);
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st);
+void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
+void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
+void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);
+void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st);
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+
+// layout conversion between the reference's [column][level] host layout and device SoA [level][column]
+// staging: dense buffer of n*nlev elements in device memory; elem = element size in bytes (1, 4 or 8)
+void launch_cols_to_soa(const void* staging, void* field, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
+                        hipStream_t st);
+void launch_soa_to_cols(const void* field, void* staging, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
+                        hipStream_t st);
+void launch_fill(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, double value, hipStream_t st);
+void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, int64_t nbase, uint64_t seed,
+                 int field_id, int mode, double amp, hipStream_t st);
+void launch_flag_reduce(const uint32_t* flags, int64_t n, uint32_t* or_out, long long* first_bad, hipStream_t st);
+void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st);
+
+}  // namespace elmk

@@ -1,0 +1,690 @@
+// k_albedo_snicar.hip - kokkos_albedo_snicar (driver/kokkos/albedo_kokkos.cc:10-376)
+//
+//   surface_albedo::init_timestep :90, soil_albedo :690, ground_albedo :155, flux_absorption_factor :171,
+//   canopy_layer_lai :215, two_stream_solver :323           (src/physics/surface_albedo_impl.hh)
+//   snow_snicar::init_timestep :9, snow_aerosol_mie_params :107, snow_radiative_transfer_solver :313,
+//   snow_albedo_radiation_factor :673, run twice (direct, diffuse)   (src/physics/snow_snicar_impl.hh)
+//
+// One thread per column.  The ~210 doubles of per-column scratch that the wrapper allocates as zero-filled
+// Views on every call (albedo_kokkos.cc:19-38) never touch memory here:
+//   * the Mie/aerosol mixing of a band and the Delta-Eddington adding-doubling solve of the same band are
+//     fused, so g_star/omega_star/tau_star shrink from [5][5] to one band of 5 layers;
+//   * the per-band absorbed fluxes flx_abs_lcl[6][5] are folded into the VIS value and the running
+//     flux-weighted NIR sum as each band finishes (same summation order as :724-741);
+//   * layer loops run over the fixed 5 snow levels with an `i >= snl_top` predicate so every per-layer
+//     array is statically indexed and lives in registers.
+// Night columns (coszen <= 0) only write the init_timestep defaults.  Lookup tables (Mie [3][5][1471] x2,
+// BC, aerosol) sit in one 355 KB device buffer that stays L2-resident; the gather index is round(snw_rds)-30.
+#include "elmk_dev.h"
+#include "elmk_kernels.h"
+
+namespace elmk {
+
+#define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
+
+constexpr double SA_MPE = 1.e-06;   // surface_albedo.h:56
+constexpr double SA_EXTKN = 0.30;   // surface_albedo.h:57
+constexpr double SN_MIN_SNW = 1.0e-30;  // snow_snicar.h:27
+constexpr int SN_RDS_MAX_TBL = 1500, SN_RDS_MIN_TBL = 30;
+// exp(-argmax), argmax = 10 (snow_snicar_impl.hh:360): the reference's constexpr value, 0x1.7cd79b5647c9bp-15
+constexpr double SN_EXP_MIN = 4.5399929762484854e-05;
+
+struct SnowOut {
+  double alb[2];         // albout (VIS, NIR)
+  double fabs_[6][2];    // flx_abs(i, {VIS, NIR})
+};
+
+// One SNICAR pass (flg_slr_in = 1 direct / 2 diffuse) for an active column (coszen > 0, h2osno > min_snw).
+// rds[] = snw_rds_lcl, ice[]/liq[] = h2osoi_*_lcl, mss[i][j] = mss_cnc_aer_in_fdb, snl_top in 0..4.
+template <int FLG>
+__device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, int snl_top, double mu_not,
+                                            const int (&rds)[5], const double (&ice)[5], const double (&liq)[5],
+                                            const double (&mss_in)[5][8], const double (&albsoi)[2], SnowOut& out,
+                                            uint32_t& err)
+{
+  const double difgauspt[8] = {0.9894009, 0.9445750, 0.8656312, 0.7554044, 0.6178762, 0.4580168, 0.2816036, 0.0950125};
+  const double difgauswt[8] = {0.0271525, 0.0622535, 0.0951585, 0.1246290, 0.1495960, 0.1691565, 0.1826034, 0.1894506};
+  const double puny = 1.0e-11;
+  const double c0 = 0.0, c1 = 1.0, c3 = 3.0, c4 = 4.0, cp5 = 0.5, cp75 = 0.75, c1p5 = 1.5, trmin = 0.001;
+  // 5-band flux weights (snow_snicar_impl.hh:710-723)
+  const double w1 = (FLG == 1) ? 0.49352158521175 : 0.58581507618433;
+  const double w2 = (FLG == 1) ? 0.18099494230665 : 0.20156903770812;
+  const double w3 = (FLG == 1) ? 0.12094898498813 : 0.10917889346386;
+  const double w4 = (FLG == 1) ? 0.20453448749347 : 0.10343699264369;
+  const double flx_wgt[5] = {1.0, w1, w2, w3, w4};
+  // incident irradiance (:88-98)
+  const double flx_slrd = (FLG == 1) ? 1.0 / (mu_not * ELM_PI) : 0.0;
+  const double flx_slri = (FLG == 1) ? 0.0 : 1.0;
+
+  double mss[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) mss[i][j] = mss_in[i][j];
+
+  double alb_nir_sum = 0.0, wgt_sum = 0.0;
+  double nir_sum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    out.fabs_[i][0] = 0.0;  // flx_abs_lcl(i,0) is zero wherever the solver does not write (i < snl_top)
+    out.fabs_[i][1] = 0.0;
+  }
+
+  const double* tsnw = tab + ((FLG == 1) ? SN_SNW_DRC : SN_SNW_DFS);
+
+#pragma unroll 1
+  for (int bnd = 0; bnd < 5; ++bnd) {
+    if (bnd == 4 || bnd == 3) {  // (:150-156)
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
+    }
+    // aerosol species 2..7 of this band (:179-210); species 0/1 (BC) depend on the layer
+    double ss_aer[8], asm_aer[8], ext_aer[8];
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+      ss_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 0 + bnd];
+      asm_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 5 + bnd];
+      ext_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 10 + bnd];
+    }
+    // ---- snow_aerosol_mie_params for this band: delta-transformed layer optics (:215-305)
+    double g_star[5], omega_star[5], tau_star[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      g_star[i] = omega_star[i] = tau_star[i] = 0.0;
+      if (i >= snl_top) {
+        const int rds_idx = rds[i] - SN_RDS_MIN_TBL;
+        const double ss_snw = tsnw[(0 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+        const double asm_snw = tsnw[(1 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+        const double ext_snw = tsnw[(2 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+        int idx_ice;
+        if (rds[i] < 125) {
+          const double tmp1 = rds[i] / 50;  // integer division as in the reference (:250)
+          idx_ice = (int)round(tmp1) - 1;
+        } else if (rds[i] < 175) {
+          idx_ice = 1;
+        } else {
+          const double tmp1 = (rds[i] / 250) + 2;  // integer division (:255)
+          idx_ice = (int)round(tmp1) - 1;
+        }
+        const int idx_ncl = 1;  // round(100/50) - 1 for both within-ice and external BC (:260-261), inside [0, 9]
+        if (idx_ice < 0) idx_ice = 0;
+        if (idx_ice > 7) idx_ice = 7;
+        const double enh_fct = tab[SN_BCENH + (idx_ice * 10 + idx_ncl) * 5 + bnd];
+        ss_aer[0] = tab[SN_BC1 + 0 + idx_ncl * 5 + bnd];
+        asm_aer[0] = tab[SN_BC1 + 50 + idx_ncl * 5 + bnd];
+        ext_aer[0] = tab[SN_BC1 + 100 + idx_ncl * 5 + bnd] * enh_fct;
+        ss_aer[1] = tab[SN_BC2 + 0 + idx_ncl * 5 + bnd];
+        asm_aer[1] = tab[SN_BC2 + 50 + idx_ncl * 5 + bnd];
+        ext_aer[1] = tab[SN_BC2 + 100 + idx_ncl * 5 + bnd];
+
+        const double L_snw = ice[i] + liq[i];
+        const double tau_snw = L_snw * ext_snw;
+        double tau_sum = 0.0, omega_sum = 0.0, g_sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double L_aer = L_snw * mss[i][j];
+          const double tau_aer = L_aer * ext_aer[j];
+          tau_sum += tau_aer;
+          omega_sum += (tau_aer * ss_aer[j]);
+          g_sum += (tau_aer * ss_aer[j] * asm_aer[j]);
+        }
+        const double tau = tau_sum + tau_snw;
+        const double omega = (1.0 / tau) * (omega_sum + (ss_snw * tau_snw));
+        const double g = (1.0 / (tau * omega)) * (g_sum + (asm_snw * ss_snw * tau_snw));
+        g_star[i] = g / (1.0 + g);
+        omega_star[i] = ((1.0 - pow(g, 2.0)) * omega) / (1.0 - (omega * pow(g, 2.0)));
+        tau_star[i] = (1.0 - (omega * pow(g, 2.0))) * tau;
+      }
+    }
+
+    // ---- snow_radiative_transfer_solver for this band (:384-667)
+    double trndir[6], trntdr[6], trndif[6], rdndif[6];
+    double rdir[5], rdif_a[5], tdir[5], tdif_a[5], trnlay[5];  // rdif_b == rdif_a, tdif_b == tdif_a (:489-490)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      trndir[i] = c0;
+      trntdr[i] = c0;
+      trndif[i] = c0;
+      rdndif[i] = c0;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      if (i == snl_top) {
+        trndir[i] = c1;
+        trntdr[i] = c1;
+        trndif[i] = c1;
+        rdndif[i] = c0;
+      }
+      rdir[i] = c0;
+      rdif_a[i] = c0;
+      tdir[i] = c0;
+      tdif_a[i] = c0;
+      trnlay[i] = c0;
+      if (i >= snl_top) {
+        if (trntdr[i] > trmin) {
+          const double ts = tau_star[i];
+          const double ws = omega_star[i];
+          const double gs = g_star[i];
+          const double lm = sqrt(c3 * (c1 - ws) * (c1 - ws * gs));
+          const double ue = c1p5 * (c1 - ws * gs) / lm;
+          const double extins = dmax(SN_EXP_MIN, exp(-lm * ts));
+          const double ne = ((ue + c1) * (ue + c1) / extins) - ((ue - c1) * (ue - c1) * extins);
+          const double R1 = (pow(ue, 2.0) - c1) * (c1 / extins - extins) / ne;
+          const double T1 = c4 * ue / ne;
+          trnlay[i] = dmax(SN_EXP_MIN, exp(-ts / mu_not));
+          double alp = cp75 * ws * mu_not * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu_not * mu_not));
+          double gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu_not * mu_not) / (c1 - lm * lm * mu_not * mu_not));
+          double apg = alp + gam;
+          double amg = alp - gam;
+          rdir[i] = apg * R1 + amg * (T1 * trnlay[i] - c1);
+          tdir[i] = apg * T1 + (amg * R1 - apg + c1) * trnlay[i];
+          double swt = c0, smr = c0, smt = c0;
+#pragma unroll
+          for (int ng = 0; ng < 8; ++ng) {
+            const double mu = difgauspt[ng];
+            const double gwt = difgauswt[ng];
+            swt = swt + mu * gwt;
+            const double trn = dmax(SN_EXP_MIN, exp(-ts / mu));
+            alp = cp75 * ws * mu * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu * mu));
+            gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu * mu) / (c1 - lm * lm * mu * mu));
+            apg = alp + gam;
+            amg = alp - gam;
+            const double rdr = apg * R1 + amg * T1 * trn - amg;
+            const double tdr = apg * T1 + amg * R1 * trn - apg * trn + trn;
+            smr = smr + mu * rdr * gwt;
+            smt = smt + mu * tdr * gwt;
+          }
+          rdif_a[i] = smr / swt;
+          tdif_a[i] = smt / swt;
+        }
+        trndir[i + 1] = trndir[i] * trnlay[i];
+        const double refkm1 = c1 / (c1 - rdndif[i] * rdif_a[i]);
+        const double tdrrdir = trndir[i] * rdir[i];
+        const double tdndif = trntdr[i] - trndir[i];
+        trntdr[i + 1] = trndir[i] * tdir[i] + (tdndif + tdrrdir * rdndif[i]) * refkm1 * tdif_a[i];
+        rdndif[i + 1] = rdif_a[i] + (tdif_a[i] * rdndif[i] * refkm1 * tdif_a[i]);
+        trndif[i + 1] = trndif[i] * refkm1 * tdif_a[i];
+      }
+    }
+
+    // upward sweep from the ground interface (:506-524)
+    double rupdir[6], rupdif[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      rupdir[i] = c0;
+      rupdif[i] = c0;
+    }
+    rupdir[5] = albsoi[1];
+    rupdif[5] = albsoi[1];
+    if (bnd == 0) {
+      rupdir[5] = albsoi[0];
+      rupdif[5] = albsoi[0];
+    }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+      if (i >= snl_top) {
+        const double refkp1 = c1 / (c1 - rdif_a[i] * rupdif[i + 1]);
+        rupdir[i] = rdir[i] + (trnlay[i] * rupdir[i + 1] + (tdir[i] - trnlay[i]) * rupdif[i + 1]) * refkp1 * tdif_a[i];
+        rupdif[i] = rdif_a[i] + tdif_a[i] * rupdif[i + 1] * refkp1 * tdif_a[i];
+      }
+    }
+
+    // net interface fluxes (:540-569); dftmp = dfdir (direct pass) or dfdif (diffuse pass) (:571-591)
+    double dftmp[6];
+    double albedo = 0.0, F_sfc_pls = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      dftmp[i] = c0;
+      if (i >= snl_top) {
+        const double refk = c1 / (c1 - rdndif[i] * rupdif[i]);
+        if (FLG == 1) {
+          double dfdir = trndir[i] + (trntdr[i] - trndir[i]) * (c1 - rupdif[i]) * refk -
+                         trndir[i] * rupdir[i] * (c1 - rdndif[i]) * refk;
+          if (dfdir < puny) dfdir = c0;
+          dftmp[i] = dfdir;
+        } else {
+          double dfdif = trndif[i] * (c1 - rupdif[i]) * refk;
+          if (dfdif < puny) dfdif = c0;
+          dftmp[i] = dfdif;
+        }
+        if (i == snl_top) {
+          if (FLG == 1) {
+            albedo = rupdir[i];
+            F_sfc_pls = (trndir[i] * rupdir[i] + (trntdr[i] - trndir[i]) * rupdif[i]) * refk;
+          } else {
+            albedo = rupdif[i];
+            F_sfc_pls = trndif[i] * rupdif[i] * refk;
+          }
+        }
+      }
+    }
+
+    // absorbed flux per layer + ground (:594-650)
+    double F_abs_sum = 0.0;
+    double fl[6];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      fl[i] = 0.0;
+      if (i >= snl_top) {
+        const double F_abs = dftmp[i] - dftmp[i + 1];
+        fl[i] = F_abs;
+        if (F_abs < -0.00001) err |= ELMK_ERR_SNICAR_NEG_ABS;
+        F_abs_sum = F_abs_sum + F_abs;
+      }
+    }
+    const double F_btm_net = dftmp[5];
+    fl[5] = F_btm_net;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i >= snl_top && fl[i] < 0.0) fl[i] = 0.0;  // underflow clamp (:640-644)
+    }
+    const double energy_sum = (mu_not * ELM_PI * flx_slrd) + flx_slri - (F_abs_sum + F_btm_net + F_sfc_pls);
+    if (fabs(energy_sum) > 0.00001) err |= ELMK_ERR_SNICAR_ENERGY;
+    if (albedo > 1.0) err |= ELMK_ERR_SNICAR_ALBEDO;
+
+    // ---- snow_albedo_radiation_factor, folded in band by band (:724-741)
+    if (bnd == 0) {
+      out.alb[0] = albedo;
+#pragma unroll
+      for (int i = 0; i < 6; i++) out.fabs_[i][0] = fl[i];
+    } else {
+      alb_nir_sum += flx_wgt[bnd] * albedo;
+      wgt_sum += flx_wgt[bnd];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        if (i >= snl_top) nir_sum[i] += flx_wgt[bnd] * fl[i];
+      }
+    }
+  }
+  out.alb[1] = alb_nir_sum / wgt_sum;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (i >= snl_top) out.fabs_[i][1] = nir_sum[i] / wgt_sum;
+  }
+  // near-IR direct albedo/absorption adjustment at high solar zenith angle (:748-757)
+  if (FLG == 1 && mu_not < 0.2588) {
+    const double sza_c1 = 0.085730 + (-0.630883) * mu_not + 1.303723 * pow(mu_not, 2.0);
+    const double sza_c0 = 1.467291 + (-3.338043) * mu_not + 6.807489 * pow(mu_not, 2.0);
+    int rtop = rds[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i == snl_top) rtop = rds[i];
+    const double sza_factor = sza_c1 * (log10(rtop * 1.0) - 6.0) + sza_c0;
+    const double flx_sza_adjust = out.alb[1] * (sza_factor - 1.0) * wgt_sum;
+    out.alb[1] *= sza_factor;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+      if (i == snl_top) out.fabs_[i][1] -= flx_sza_adjust;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_albedo_snicar(const DevState* __restrict__ S)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S->ncols) return;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
+
+  uint32_t err = 0;
+  const double coszen = S->coszen[c];
+  const double elai = S->elai[c], esai = S->esai[c];
+
+  // ---- canopy_layer_lai (:215-319), nlevcan == 1: one big-leaf layer
+  S->nrad[c] = 1;
+  S->tlai_z[c] = elai;
+  // (laisum/saisum of a single layer equal elai/esai exactly: the reference's consistency throw cannot fire)
+
+  // ---- init_timestep (:90-151): night / default values
+  double vcmaxcintsun = 0.0;
+  double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
+  if (elai > 0.0) {
+    vcmaxcintsha /= elai;
+  } else {
+    vcmaxcintsha = 0.0;
+  }
+
+  if (!(coszen > 0.0)) {
+    // nothing after init_timestep runs at night except snow_albedo_radiation_factor's "no sun" branch (:758-765)
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {
+      LV(albsod, ib) = 0.0;
+      LV(albsoi, ib) = 0.0;
+      LV(albgrd, ib) = 0.0;
+      LV(albgri, ib) = 0.0;
+      LV(albd, ib) = 1.0;
+      LV(albi, ib) = 1.0;
+      LV(fabd, ib) = 0.0;
+      LV(fabi, ib) = 0.0;
+      LV(fabi_sun, ib) = 0.0;
+      LV(fabi_sha, ib) = 0.0;
+      LV(ftdd, ib) = 0.0;
+      LV(ftid, ib) = 0.0;
+      LV(ftii, ib) = 0.0;
+      LV(albsnd, ib) = 0.0;
+      LV(albsni, ib) = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      LV(flx_absdv, i) = 0.0;
+      LV(flx_absdn, i) = 0.0;
+      LV(flx_absiv, i) = 0.0;
+      LV(flx_absin, i) = 0.0;
+    }
+    S->vcmaxcintsun[c] = vcmaxcintsun;
+    S->vcmaxcintsha[c] = vcmaxcintsha;
+    S->fsun_z[c] = 0.0;
+    S->fabd_sun_z[c] = 0.0;
+    S->fabd_sha_z[c] = 0.0;
+    S->fabi_sun_z[c] = 0.0;
+    S->fabi_sha_z[c] = 0.0;
+    return;
+  }
+
+  // =========================== sunlit column ===========================
+  const double h2osno = S->h2osno[c];
+  const double frac_sno = S->frac_sno[c];
+  const int snl = S->snl[c];
+
+  // ---- soil_albedo (:690-754)
+  double albsod[2], albsoi[2];
+  {
+    const double albice[2] = {0.8, 0.55};
+    const double alblak[2] = {0.60, 0.40};
+    const double alblakwi[2] = {0.10, 0.10};
+    if (L.ltype == istsoil || L.ltype == istcrop) {
+      const int col = S->isoicol[c];
+      const double inc = dmax(0.11 - 0.40 * LV(h2osoi_vol, 0), 0.0);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        albsod[ib] = dmin(S->albsat[col][ib] + inc, S->albdry[col][ib]);
+        albsoi[ib] = albsod[ib];
+      }
+    } else if (L.ltype == istice || L.ltype == istice_mec) {
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        albsod[ib] = albice[ib];
+        albsoi[ib] = albsod[ib];
+      }
+    } else if (L.ltype == istdlak && snl == 0) {
+      const double t_grnd = S->t_grnd[c];
+      const double sicefr = 1.0 - exp(-95.6 * (TFRZ - t_grnd) / TFRZ);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        albsod[ib] = sicefr * alblak[ib] + (1.0 - sicefr) * dmax(alblakwi[ib], 0.05 / (dmax(0.001, coszen) + 0.15));
+        albsoi[ib] = sicefr * alblak[ib] + (1.0 - sicefr) * dmax(alblakwi[ib], 0.10);
+      }
+    } else {
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        albsod[ib] = alblak[ib];
+        albsoi[ib] = albsod[ib];
+      }
+    }
+  }
+
+  // ---- SNICAR, direct then diffuse (albedo_kokkos.cc:96-301)
+  SnowOut sd, si;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
+    si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
+  }
+  if (h2osno > SN_MIN_SNW) {
+    int rds[5] = {0, 0, 0, 0, 0};
+    double ice[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, liq[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int snl_top;
+    if (snl == 0) {  // fictitious fresh-snow layer (flg_nosnl = 1), snow_snicar_impl.hh:42-48
+      snl_top = NLEVSNO - 1;
+      ice[4] = h2osno;
+      liq[4] = 0.0;
+      rds[4] = (int)round(SNW_RDS_MIN);
+    } else {
+      snl_top = NLEVSNO - snl;
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        // the reference copies all five levels; only i >= snl_top is ever read
+        if (i >= snl_top) {
+          liq[i] = LV(h2osoi_liq, i);
+          ice[i] = LV(h2osoi_ice, i);
+          rds[i] = (int)round(LV(snw_rds, i));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      if (i >= snl_top && (rds[i] < SN_RDS_MIN_TBL || rds[i] > SN_RDS_MAX_TBL)) {
+        err |= ELMK_ERR_SNICAR_RDS;  // the reference throws (:74-78); clamp so the table gather stays in range
+        rds[i] = rds[i] < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : SN_RDS_MAX_TBL;
+      }
+    }
+    const double mu_not = dmax(coszen, 0.01);
+    // aerosol concentrations (surface_albedo_impl.hh:141-150): OC species 2,3 are ignored
+    double mss[5][8];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
+      if (i >= snl_top) {
+        mss[i][0] = LV(cnc_bcphi, i);
+        mss[i][1] = LV(cnc_bcpho, i);
+        mss[i][4] = LV(cnc_dst1, i);
+        mss[i][5] = LV(cnc_dst2, i);
+        mss[i][6] = LV(cnc_dst3, i);
+        mss[i][7] = LV(cnc_dst4, i);
+      }
+    }
+    snicar_pass<1>(S->snicar, snl_top, mu_not, rds, ice, liq, mss, albsoi, sd, err);
+    snicar_pass<2>(S->snicar, snl_top, mu_not, rds, ice, liq, mss, albsoi, si, err);
+  } else if (h2osno < SN_MIN_SNW && h2osno > 0.0) {  // (:758-761)
+    sd.alb[0] = si.alb[0] = albsoi[0];
+    sd.alb[1] = si.alb[1] = albsoi[1];
+  } else {
+    sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
+  }
+
+  // ---- ground_albedo (:155-167) and flux_absorption_factor (:171-211, subgridflag == 1)
+  double albgrd[2], albgri[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    albgrd[ib] = albsod[ib] * (1.0 - frac_sno) + sd.alb[ib] * frac_sno;
+    albgri[ib] = albsoi[ib] * (1.0 - frac_sno) + si.alb[ib] * frac_sno;
+    LV(albsod, ib) = albsod[ib];
+    LV(albsoi, ib) = albsoi[ib];
+    LV(albsnd, ib) = sd.alb[ib];
+    LV(albsni, ib) = si.alb[ib];
+    LV(albgrd, ib) = albgrd[ib];
+    LV(albgri, ib) = albgri[ib];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double dv, dn, iv, in;
+    if (L.ltype == istdlak) {
+      dv = sd.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[0]) * (sd.fabs_[i][0] / (1.0 - sd.alb[0])));
+      iv = si.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[0]) * (si.fabs_[i][0] / (1.0 - si.alb[0])));
+      dn = sd.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[1]) * (sd.fabs_[i][1] / (1.0 - sd.alb[1])));
+      in = si.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[1]) * (si.fabs_[i][1] / (1.0 - si.alb[1])));
+    } else {
+      dv = sd.fabs_[i][0] * (1.0 - sd.alb[0]);
+      iv = si.fabs_[i][0] * (1.0 - si.alb[0]);
+      dn = sd.fabs_[i][1] * (1.0 - sd.alb[1]);
+      in = si.fabs_[i][1] * (1.0 - si.alb[1]);
+    }
+    LV(flx_absdv, i) = dv;
+    LV(flx_absdn, i) = dn;
+    LV(flx_absiv, i) = iv;
+    LV(flx_absin, i) = in;
+  }
+
+  // ---- two_stream_solver (:323-687), nlevcan == 1
+  double albd[2], albi[2], ftdd[2], ftid[2], ftii[2], fabd[2], fabi[2], fabi_sun[2], fabi_sha[2];
+  double fsun_z = 0.0, fabd_sun_z = 0.0, fabd_sha_z = 0.0, fabi_sun_z = 0.0, fabi_sha_z = 0.0;
+  const bool soilcrop = (L.ltype == istsoil || L.ltype == istcrop);
+  if (soilcrop && (elai + esai) > 0.0) {  // vegsol
+    const double* __restrict__ A = S->pft_alb[S->vtype[c]];  // rhol[2] rhos[2] taul[2] taus[2] xl
+    const double t_veg = S->t_veg[c], fwet = S->fwet[c];
+    const double omegas[2] = {0.8, 0.4};
+    const double betads = 0.5, betais = 0.5;
+    const double wl = elai / dmax(elai + esai, SA_MPE);
+    const double ws = esai / dmax(elai + esai, SA_MPE);
+    const double cosz = dmax(0.001, coszen);
+    double chil = dmin(dmax(A[8], -0.4), 0.6);
+    if (fabs(chil) <= 0.01) chil = 0.01;
+    const double phi1 = 0.5 - 0.633 * chil - 0.330 * chil * chil;
+    const double phi2 = 0.877 * (1.0 - 2.0 * phi1);
+    const double gdir = phi1 + phi2 * cosz;
+    const double twostext = gdir / cosz;
+    const double avmu = (1.0 - phi1 / phi2 * log((phi1 + phi2) / phi1)) / phi2;
+    const double temp0 = gdir + phi2 * cosz;
+    const double temp1 = phi1 * cosz;
+    const double temp2 = (1.0 - temp1 / temp0 * log((temp1 + temp0) / temp1));
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {
+      const double rho = dmax(A[0 + ib] * wl + A[2 + ib] * ws, SA_MPE);
+      const double tau = dmax(A[4 + ib] * wl + A[6 + ib] * ws, SA_MPE);
+      const double omegal = rho + tau;
+      const double asu = 0.5 * omegal * gdir / temp0 * temp2;
+      const double betadl = (1.0 + avmu * twostext) / (omegal * avmu * twostext) * asu;
+      const double betail = 0.5 * ((rho + tau) + (rho - tau) * pow(((1.0 + chil) / 2.0), 2.0)) / omegal;
+      double tmp0, tmp1, tmp2;
+      if (t_veg > TFRZ) {
+        tmp0 = omegal;
+        tmp1 = betadl;
+        tmp2 = betail;
+      } else {
+        tmp0 = (1.0 - fwet) * omegal + fwet * omegas[ib];
+        tmp1 = ((1.0 - fwet) * omegal * betadl + fwet * omegas[ib] * betads) / tmp0;
+        tmp2 = ((1.0 - fwet) * omegal * betail + fwet * omegas[ib] * betais) / tmp0;
+      }
+      const double omega = tmp0;
+      const double betad = tmp1;
+      const double betai = tmp2;
+      const double b = 1.0 - omega + omega * betai;
+      const double c1 = omega * betai;
+      tmp0 = avmu * twostext;
+      const double d = tmp0 * omega * betad;
+      const double f = tmp0 * omega * (1.0 - betad);
+      tmp1 = b * b - c1 * c1;
+      const double h = sqrt(tmp1) / avmu;
+      const double sigma = tmp0 * tmp0 - tmp1;
+      const double p1 = b + avmu * h;
+      const double p2 = b - avmu * h;
+      const double p3 = b + tmp0;
+      const double p4 = b - tmp0;
+      double t1 = dmin(h * (elai + esai), 40.0);
+      const double s1 = exp(-t1);
+      t1 = dmin(twostext * (elai + esai), 40.0);
+      const double s2 = exp(-t1);
+      // direct beam
+      double u1 = b - c1 / albgrd[ib];
+      double u2 = b - c1 * albgrd[ib];
+      const double u3 = f + c1 * albgrd[ib];
+      tmp2 = u1 - avmu * h;
+      double tmp3 = u1 + avmu * h;
+      double d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
+      double tmp4 = u2 + avmu * h;
+      double tmp5 = u2 - avmu * h;
+      double d2 = tmp4 / s1 - tmp5 * s1;
+      const double h1 = -d * p4 - c1 * f;
+      const double tmp6 = d - h1 * p3 / sigma;
+      const double tmp7 = (d - c1 - h1 / sigma * (u1 + tmp0)) * s2;
+      const double h2 = (tmp6 * tmp2 / s1 - p2 * tmp7) / d1;
+      const double h3 = -(tmp6 * tmp3 * s1 - p1 * tmp7) / d1;
+      const double h4 = -f * p3 - c1 * d;
+      const double tmp8 = h4 / sigma;
+      const double tmp9 = (u3 - tmp8 * (u2 - tmp0)) * s2;
+      const double h5 = -(tmp8 * tmp4 / s1 + tmp9) / d2;
+      const double h6 = (tmp8 * tmp5 * s1 + tmp9) / d2;
+      albd[ib] = h1 / sigma + h2 + h3;
+      ftid[ib] = h4 * s2 / sigma + h5 * s1 + h6 / s1;
+      ftdd[ib] = s2;
+      fabd[ib] = 1.0 - albd[ib] - (1.0 - albgrd[ib]) * ftdd[ib] - (1.0 - albgri[ib]) * ftid[ib];
+      double a1 = h1 / sigma * (1.0 - s2 * s2) / (2.0 * twostext) + h2 * (1.0 - s2 * s1) / (twostext + h) +
+                  h3 * (1.0 - s2 / s1) / (twostext - h);
+      double a2 = h4 / sigma * (1.0 - s2 * s2) / (2.0 * twostext) + h5 * (1.0 - s2 * s1) / (twostext + h) +
+                  h6 * (1.0 - s2 / s1) / (twostext - h);
+      const double fabd_sun = (1.0 - omega) * (1.0 - s2 + 1.0 / avmu * (a1 + a2));
+      const double fabd_sha = fabd[ib] - fabd_sun;  // wrapper-local in the reference (albedo_kokkos.cc:27-28)
+      // diffuse
+      u1 = b - c1 / albgri[ib];
+      u2 = b - c1 * albgri[ib];
+      tmp2 = u1 - avmu * h;
+      tmp3 = u1 + avmu * h;
+      d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
+      tmp4 = u2 + avmu * h;
+      tmp5 = u2 - avmu * h;
+      d2 = tmp4 / s1 - tmp5 * s1;
+      const double h7 = (c1 * tmp2) / (d1 * s1);
+      const double h8 = (-c1 * tmp3 * s1) / d1;
+      const double h9 = tmp4 / (d2 * s1);
+      const double h10 = (-tmp5 * s1) / d2;
+      albi[ib] = h7 + h8;
+      ftii[ib] = h9 * s1 + h10 / s1;
+      fabi[ib] = 1.0 - albi[ib] - (1.0 - albgri[ib]) * ftii[ib];
+      a1 = h7 * (1.0 - s2 * s1) / (twostext + h) + h8 * (1.0 - s2 / s1) / (twostext - h);
+      a2 = h9 * (1.0 - s2 * s1) / (twostext + h) + h10 * (1.0 - s2 / s1) / (twostext - h);
+      fabi_sun[ib] = (1.0 - omega) / avmu * (a1 + a2);
+      fabi_sha[ib] = fabi[ib] - fabi_sun[ib];
+      if (ib == 0) {
+        fsun_z = (1.0 - s2) / t1;
+        const double laisum = elai + esai;
+        fabd_sun_z = fabd_sun / (fsun_z * laisum);
+        fabi_sun_z = fabi_sun[ib] / (fsun_z * laisum);
+        fabd_sha_z = fabd_sha / ((1.0 - fsun_z) * laisum);
+        fabi_sha_z = fabi_sha[ib] / ((1.0 - fsun_z) * laisum);
+        const double extkb = twostext;
+        vcmaxcintsun = (1.0 - exp(-(SA_EXTKN + extkb) * elai)) / (SA_EXTKN + extkb);
+        vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN - vcmaxcintsun;
+        if (elai > 0.0) {
+          vcmaxcintsun = vcmaxcintsun / (fsun_z * elai);
+          vcmaxcintsha = vcmaxcintsha / ((1.0 - fsun_z) * elai);
+        } else {
+          vcmaxcintsun = 0.0;
+          vcmaxcintsha = 0.0;
+        }
+      }
+    }
+  } else {  // novegsol (:672-686)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      fabd[ib] = 0.0;
+      fabi[ib] = 0.0;
+      fabi_sun[ib] = 0.0;
+      fabi_sha[ib] = 0.0;
+      ftdd[ib] = 1.0;
+      ftid[ib] = 0.0;
+      ftii[ib] = 1.0;
+      albd[ib] = albgrd[ib];
+      albi[ib] = albgri[ib];
+    }
+  }
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    LV(albd, ib) = albd[ib];
+    LV(albi, ib) = albi[ib];
+    LV(ftdd, ib) = ftdd[ib];
+    LV(ftid, ib) = ftid[ib];
+    LV(ftii, ib) = ftii[ib];
+    LV(fabd, ib) = fabd[ib];
+    LV(fabi, ib) = fabi[ib];
+    LV(fabi_sun, ib) = fabi_sun[ib];
+    LV(fabi_sha, ib) = fabi_sha[ib];
+  }
+  S->vcmaxcintsun[c] = vcmaxcintsun;
+  S->vcmaxcintsha[c] = vcmaxcintsha;
+  S->fsun_z[c] = fsun_z;
+  S->fabd_sun_z[c] = fabd_sun_z;
+  S->fabd_sha_z[c] = fabd_sha_z;
+  S->fabi_sun_z[c] = fabi_sun_z;
+  S->fabi_sha_z[c] = fabi_sha_z;
+  if (err) S->err_flags[c] |= err;
+}
+
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_albedo_snicar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S);
+}
+
+}  // namespace elmk

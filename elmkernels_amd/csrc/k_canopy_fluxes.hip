@@ -1,0 +1,749 @@
+// k_canopy_fluxes.hip - kokkos_canopy_fluxes (driver/kokkos/canopy_fluxes_kokkos.cc:6-265)
+//
+//   canopy_fluxes::initialize_flux      src/physics/canopy_fluxes_impl.hh:95-184
+//     soil_moist_stress::calc_effective_soilporosity / calc_volumetric_h2oliq / calc_root_moist_stress
+//                                       src/physics/soil_moist_stress_impl.hh:62-133
+//   canopy_fluxes::stability_iteration  canopy_fluxes_impl.hh:187-452  (leaf-temperature Newton loop, <= 41 trips)
+//     photosynthesis::photosynthesis    src/physics/photosynthesis_impl.hh:9-282 (called twice per trip)
+//       hybrid :517, ci_func :308, brent :396, quadratic :286, ft/fth/fth25 :623-635
+//   canopy_fluxes::compute_flux         canopy_fluxes_impl.hh:456-540
+//
+// One thread per column.  The kernel is the compute-bound one of the timestep (fp64 transcendentals and
+// data-dependent trip counts), so the work is organised to cut instruction count without changing any
+// rounded result:
+//   * every quantity that the reference recomputes inside photosynthesis() from loop-invariant inputs
+//     (PFT constants, t10, dayl_factor, forc_pbot, thm) is evaluated once per column (PsnInv);
+//   * the t_veg-dependent Arrhenius factors, identical for the sunlit and shaded call of one trip, are
+//     evaluated once per trip (PsnTemp) - 11 exp instead of 22;
+//   * the 30 ViewD1(ncols) temporaries of the wrapper (:11-40) and the 15-level work arrays stay in registers.
+// The arithmetic of each expression (operand order, parenthesisation) is the reference's.
+#include "elmk_dev.h"
+#include "elmk_kernels.h"
+
+namespace elmk {
+
+#define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
+
+// photosynthesis_impl.hh:623-635
+__device__ __forceinline__ double psn_ft(double tl, double ha)
+{
+  return exp(ha / (RGAS * 1.0e-3 * (TFRZ + 25.0)) * (1.0 - (TFRZ + 25.0) / tl));
+}
+__device__ __forceinline__ double psn_fth(double tl, double hd, double se, double scaleFactor)
+{
+  return scaleFactor / (1.0 + exp((-hd + se * tl) / (RGAS * 1.0e-3 * tl)));
+}
+__device__ __forceinline__ double psn_fth25(double hd, double se)
+{
+  return 1.0 + exp((-hd + se * (TFRZ + 25.0)) / (RGAS * 1.0e-3 * (TFRZ + 25.0)));
+}
+
+// photosynthesis_impl.hh:286-302
+__device__ __forceinline__ void psn_quadratic(double a, double b, double c, double& r1, double& r2, uint32_t& err)
+{
+  if (a == 0.0) err |= ELMK_ERR_PSN_QUADRATIC;
+  double q;
+  if (b >= 0.0) {
+    q = -0.5 * (b + sqrt(b * b - 4.0 * a * c));
+  } else {
+    q = -0.5 * (b - sqrt(b * b - 4.0 * a * c));
+  }
+  r1 = q / a;
+  if (q != 0.0) {
+    r2 = c / q;
+  } else {
+    r2 = 1.0e36;
+  }
+}
+
+// per-column, iteration-invariant part of photosynthesis() (:22-61, :109-114, :135, :152-154)
+struct PsnInv {
+  bool c3flag;
+  double vcmax25top, jmax25top, tpu25top, kp25top, lmr25top;
+  double vcmaxse, jmaxse, tpuse, vcmaxc, jmaxc, tpuc, lmrc;
+  double cf, kc25, ko25, cp25;
+  // PFT constants used per trip
+  double vcmaxha, jmaxha, tpuha, lmrha, vcmaxhd, jmaxhd, tpuhd, lmrhd, lmrse, kcha, koha, cpha;
+  double qe, theta_cj, bbbopt, mbbopt;
+};
+
+// per-trip temperature factors shared by the sunlit and shaded call
+struct PsnTemp {
+  double ft_vcmax, fth_vcmax, ft_jmax, fth_jmax, ft_tpu, fth_tpu, ft_lmr, fth_lmr;
+  double p2, e_lmr_c4, e_vc4a, e_vc4b;  // C4 forms (:94-95, :120-124)
+  double kc, ko, cp;
+};
+
+// the by-reference argument pack of ci_func / brent / hybrid
+struct CiCtx {
+  double gb_mol, je, cair, oair, lmr_z, par_z, rh_can, vcmax_z, forc_pbot, cp, kc, ko, qe, tpu_z, kp_z, theta_cj, bbb, mbb;
+  bool c3flag;
+  double gs_mol, ac, aj, ap, ag, an;
+  uint32_t err;
+};
+
+// photosynthesis_impl.hh:308-390
+__device__ __forceinline__ double ci_func(double ci, CiCtx& k)
+{
+  const double theta_ip = 0.95;
+  if (k.c3flag) {
+    k.ac = k.vcmax_z * dmax(ci - k.cp, 0.0) / (ci + k.kc * (1.0 + k.oair / k.ko));
+    k.aj = k.je * dmax(ci - k.cp, 0.0) / (4.0 * ci + 8.0 * k.cp);
+    k.ap = 3.0 * k.tpu_z;
+  } else {
+    k.ac = k.vcmax_z;
+    k.aj = k.qe * k.par_z * 4.6;
+    k.ap = k.kp_z * dmax(ci, 0.0) / k.forc_pbot;
+  }
+  double r1, r2;
+  psn_quadratic(k.theta_cj, -(k.ac + k.aj), k.ac * k.aj, r1, r2, k.err);
+  const double ai = dmin(r1, r2);
+  psn_quadratic(theta_ip, -(ai + k.ap), ai * k.ap, r1, r2, k.err);
+  k.ag = dmin(r1, r2);
+  k.an = k.ag - k.lmr_z;
+  if (k.an < 0.0) return 0.0;
+  double cs = k.cair - 1.4 / k.gb_mol * k.an * k.forc_pbot;
+  cs = dmax(cs, 1.e-6);
+  const double aquad = cs;
+  const double bquad = cs * (k.gb_mol - k.bbb) - k.mbb * k.an * k.forc_pbot;
+  const double cquad = -k.gb_mol * (cs * k.bbb + k.mbb * k.an * k.forc_pbot * k.rh_can);
+  psn_quadratic(aquad, bquad, cquad, r1, r2, k.err);
+  k.gs_mol = dmax(r1, r2);
+  return ci - k.cair + k.an * k.forc_pbot * (1.4 * k.gs_mol + 1.6 * k.gb_mol) / (k.gb_mol * k.gs_mol);
+}
+
+// photosynthesis_impl.hh:396-511
+__device__ __noinline__ double psn_brent(double x1, double x2, double f1, double f2, double tol, CiCtx& k)
+{
+  const int ITMAX = 20;
+  const double EPS = 1.0e-2;
+  double d = 0.0, e = 0.0, p, q, r, s, tol1, xm;
+  double a = x1, b = x2, fa = f1, fb = f2;
+  if ((fa > 0.0 && fb > 0.0) || (fa < 0.0 && fb < 0.0)) k.err |= ELMK_ERR_PSN_BRENT_BRACKET;
+  double c = b, fc = fb;
+  int iter = 0;
+  while (iter != ITMAX) {
+    iter += 1;
+    if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) {
+      c = a;
+      fc = fa;
+      d = b - a;
+      e = d;
+    }
+    if (fabs(fc) < fabs(fb)) {
+      a = b;
+      b = c;
+      c = a;
+      fa = fb;
+      fb = fc;
+      fc = fa;
+    }
+    tol1 = 2.0 * EPS * fabs(b) + 0.5 * tol;
+    xm = 0.5 * (c - b);
+    if (fabs(xm) <= tol1 || fb == 0.0) return b;
+    if (fabs(e) >= tol1 && fabs(fa) > fabs(fb)) {
+      s = fb / fa;
+      if (a == c) {
+        p = 2.0 * xm * s;
+        q = 1.0 - s;
+      } else {
+        q = fa / fc;
+        r = fb / fc;
+        p = s * (2.0 * xm * q * (q - r) - (b - a) * (r - 1.0));
+        q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) q *= -1.0;
+      p = fabs(p);
+      if (2.0 * p < dmin(3.0 * xm * q - fabs(tol1 * q), fabs(e * q))) {
+        e = d;
+        d = p / q;
+      } else {
+        d = xm;
+        e = d;
+      }
+    } else {
+      d = xm;
+      e = d;
+    }
+    a = b;
+    fa = fb;
+    if (fabs(d) > tol1) {
+      b = b + d;
+    } else {
+      b = b + copysign(tol1, xm);
+    }
+    fb = ci_func(b, k);
+    if (fb == 0.0) break;
+  }
+  return b;
+}
+
+// photosynthesis_impl.hh:517-620 (x0 is only an output in the reference; its final value is never read again,
+// what survives the solve is the CiCtx state of the LAST ci_func evaluation)
+__device__ __forceinline__ void psn_hybrid(double x0, CiCtx& k)
+{
+  const double eps = 1.0e-2;
+  const double eps1 = 1.0e-4;
+  const int itmax = 40;
+  double f0 = ci_func(x0, k);
+  if (f0 == 0.0) return;
+  double minx = x0, minf = f0;
+  double x1 = x0 * 0.99;
+  double f1 = ci_func(x1, k);
+  if (f1 == 0.0) return;
+  if (f1 < minf) {
+    minx = x1;
+    minf = f1;
+  }
+  int iter = 0;
+  for (;;) {
+    iter += 1;
+    const double dx = -f1 * (x1 - x0) / (f1 - f0);
+    const double x = x1 + dx;
+    const double tol = fabs(x) * eps;
+    if (fabs(dx) < tol) break;
+    x0 = x1;
+    f0 = f1;
+    x1 = x;
+    f1 = ci_func(x1, k);
+    if (f1 < minf) {
+      minx = x1;
+      minf = f1;
+    }
+    if (fabs(f1) <= eps1) break;
+    if (f1 * f0 < 0.0) {
+      (void)psn_brent(x0, x1, f0, f1, tol, k);
+      break;
+    }
+    if (iter > itmax) {
+      (void)ci_func(minx, k);
+      break;
+    }
+  }
+}
+
+// photosynthesis() for one phase (sunlit or shaded), nlevcan == 1 (:63-282)
+__device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, int nrad, double forc_pbot, double esat_tv,
+                                            double eair, double oair, double cair, double rb, double btran,
+                                            double vcmaxcint, double par_z, double lai_z, uint32_t& err)
+{
+  if (nrad <= 0) return 0.0;  // laican == 0 -> rs = 0 (:266-281)
+  const double fnps = 0.15;
+  const double theta_psii = 0.7;
+  const double nscaler = vcmaxcint;
+  const double lmr25 = I.lmr25top * nscaler;
+  double lmr_z, vcmax_z, jmax_z, tpu_z, kp_z;
+  if (I.c3flag) {
+    lmr_z = lmr25 * T.ft_lmr * T.fth_lmr;
+  } else {
+    lmr_z = lmr25 * T.p2;
+    lmr_z /= (1.0 + T.e_lmr_c4);
+  }
+  if (par_z <= 0.0) {
+    vcmax_z = 0.0;
+    jmax_z = 0.0;
+    tpu_z = 0.0;
+    kp_z = 0.0;
+  } else {
+    const double vcmax25 = I.vcmax25top * nscaler;
+    const double jmax25 = I.jmax25top * nscaler;
+    const double tpu25 = I.tpu25top * nscaler;
+    const double kp25 = I.kp25top * nscaler;
+    vcmax_z = vcmax25 * T.ft_vcmax * T.fth_vcmax;  // overwritten for C4 just below, as in the reference (:115-123)
+    jmax_z = jmax25 * T.ft_jmax * T.fth_jmax;
+    tpu_z = tpu25 * T.ft_tpu * T.fth_tpu;
+    if (!I.c3flag) {
+      vcmax_z = vcmax25 * T.p2;
+      vcmax_z /= (1.0 + T.e_vc4a);
+      vcmax_z /= (1.0 + T.e_vc4b);
+    }
+    kp_z = kp25 * T.p2;
+  }
+  vcmax_z *= btran;
+  lmr_z *= btran;
+
+  const double gb = 1.0 / rb;
+  const double gb_mol = gb * I.cf;
+  const double bbb = dmax(I.bbbopt * btran, 1.0);
+  const double rsmax0 = 2.0e4;
+  double rs_z;
+  if (par_z <= 0.0) {
+    rs_z = dmin(rsmax0, 1.0 / bbb * I.cf);
+  } else {
+    const double ceair = dmin(eair, esat_tv);
+    const double rh_can = ceair / esat_tv;
+    const double qabs = 0.5 * (1.0 - fnps) * par_z * 4.6;
+    double r1, r2;
+    psn_quadratic(theta_psii, -(qabs + jmax_z), qabs * jmax_z, r1, r2, err);
+    const double je = dmin(r1, r2);
+    const double ci0 = I.c3flag ? 0.7 * cair : 0.4 * cair;
+    CiCtx k;
+    k.gb_mol = gb_mol;
+    k.je = je;
+    k.cair = cair;
+    k.oair = oair;
+    k.lmr_z = lmr_z;
+    k.par_z = par_z;
+    k.rh_can = rh_can;
+    k.vcmax_z = vcmax_z;
+    k.forc_pbot = forc_pbot;
+    k.cp = T.cp;
+    k.kc = T.kc;
+    k.ko = T.ko;
+    k.qe = I.qe;
+    k.tpu_z = tpu_z;
+    k.kp_z = kp_z;
+    k.theta_cj = I.theta_cj;
+    k.bbb = bbb;
+    k.mbb = I.mbbopt;
+    k.c3flag = I.c3flag;
+    k.gs_mol = 0.0;
+    k.ac = k.aj = k.ap = k.ag = k.an = 0.0;
+    k.err = 0;
+    psn_hybrid(ci0, k);
+    err |= k.err;
+    double gs_mol = k.gs_mol;
+    const double an = k.an;
+    if (an < 0.0) gs_mol = bbb;
+    double cs = cair - 1.4 / gb_mol * an * forc_pbot;
+    cs = dmax(cs, 1.0e-6);
+    const double gs = gs_mol / I.cf;
+    rs_z = dmin(1.0 / gs, rsmax0);
+    if (gs_mol < 0.0) err |= ELMK_ERR_PSN_NEG_GS;
+    const double hs = (gb_mol * ceair + gs_mol * esat_tv) / ((gb_mol + gs_mol) * esat_tv);
+    const double gs_mol_err = I.mbbopt * dmax(an, 0.0) * hs / cs * forc_pbot + bbb;
+    if (fabs(gs_mol - gs_mol_err) > 1.0e-01) err |= ELMK_WARN_PSN_BALL_BERRY;
+  }
+  // canopy sums over the single layer (:255-281)
+  double laican = 0.0, gscan = 0.0;
+  gscan += lai_z / (rb + rs_z);
+  laican += lai_z;
+  if (laican > 0.0) return laican / gscan - rb;
+  return 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restrict__ S, double dtime)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S->ncols) return;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  if (L.lakpoi) return;
+  const int fvn = S->frac_veg_nosno[c];
+
+  if (L.urbpoi || fvn == 0) {
+    // initialize_flux, bare branch (:117-128) + compute_flux's unconditional reset (:474-478)
+    if (!L.urbpoi) {
+      S->btran[c] = 0.0;
+      S->t_veg[c] = S->forc_tbot[c];
+#pragma unroll
+      for (int i = 0; i < NLEVGRND; i++) LV(rootr, i) = 0.0;
+    }
+    S->cgrnd[c] = 0.0;
+    S->cgrnds[c] = 0.0;
+    S->cgrndl[c] = 0.0;
+    return;
+  }
+
+  uint32_t err = 0;
+  const int snl = S->snl[c];
+  const int vt = S->vtype[c];
+  const double* __restrict__ P = S->pft_psn[vt];
+
+  const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c], forc_t = S->forc_tbot[c], forc_th = S->forc_thbot[c];
+  const double forc_po2 = derive_forc_po2(forc_pbot);
+  const double forc_pco2 = derive_forc_pco2(forc_pbot);
+  const double forc_rho = derive_forc_rho(forc_pbot, forc_q, forc_t);
+  const double thm = S->thm[c], thv = S->thv[c];
+  const double elai = S->elai[c], esai = S->esai[c], emv = S->emv[c], emg = S->emg[c], qg = S->qg[c], t_grnd = S->t_grnd[c];
+  const double forc_lwrad = S->forc_lwrad[c], z0mg = S->z0mg[c];
+  const double hgt_u = S->forc_hgt_u_patch[c], hgt_t = S->forc_hgt_t_patch[c], hgt_q = S->forc_hgt_q_patch[c];
+
+  // ================= initialize_flux, vegetated branch (:129-182) =================
+  double btran = 0.0;  // btran0
+  const double dl = S->dayl, mdl = S->max_dayl;
+  const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
+
+  // soil moisture stress over the 15 ground levels; rootr stays in registers until normalised
+  const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
+  double rootr[NLEVGRND];
+  double t_soi0 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NLEVGRND; i++) {
+    const double watsat = LV(watsat, i);
+    const double dzi = LV(dz, NLEVSNO + i);
+    // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
+    const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
+    const double eff_por = watsat - vol_ice;
+    LV(eff_porosity, i) = eff_por;
+    // calc_volumetric_h2oliq (:77-86)
+    const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
+    // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
+    const double tsoi = LV(t_soisno, NLEVSNO + i);
+    if (i == 0) t_soi0 = tsoi;
+    if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
+      rootr[i] = 0.0;
+    } else {
+      const double s_node = dmax(liqvol / eff_por, 0.01);
+      double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
+      smp_node = dmax(smpsc, smp_node);
+      const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
+      rootr[i] = LV(rootfr, i) * rresis;
+      btran += dmax(rootr[i], 0.0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NLEVGRND; i++) {
+    double r = rootr[i];
+    if (btran > 0.0) {
+      r /= btran;
+    } else {
+      r = 0.0;
+    }
+    LV(rootr, i) = r;
+  }
+  const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
+
+  // canopy roughness blend
+  const double tlsai_crit = 2.0;
+  const double lt = dmin(elai + esai, tlsai_crit);
+  const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
+  double displa = S->displa[c];
+  displa *= egvf;
+  double z0mv = S->z0mv[c];
+  z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(z0mg));
+  const double z0hv = z0mv, z0qv = z0mv;
+  S->displa[c] = displa;
+  S->z0mv[c] = z0mv;
+  S->z0hv[c] = z0hv;
+  S->z0qv[c] = z0qv;
+
+  const double air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * forc_lwrad;
+  const double bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
+  const double cir = emv * emg * STEBOL;
+
+  double t_veg = S->t_veg[c];
+  double el, deldT, qsatl, qsatldT;
+  qsat(t_veg, forc_pbot, el, deldT, qsatl, qsatldT);
+
+  double taf = (t_grnd + thm) / 2.0;
+  double qaf = (forc_q + qg) / 2.0;
+  const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
+  const double ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+  double dth = thm - taf;
+  double dqh = forc_q - qaf;
+  double delq = qg - qaf;
+  const double dthv = dth * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * dqh;
+  const double zldis = hgt_u - displa;
+  if (!(zldis >= 0.0)) err |= ELMK_ERR_CANFLX_FORC_HGT;
+  double um, obu;
+  monin_obukhov_length(ur, thv, dthv, zldis, z0mv, um, obu);
+
+  // ================= loop-invariant photosynthesis setup (photosynthesis_impl.hh:22-61,109-114,135,152-154) =========
+  PsnInv I;
+  {
+    const double t10 = S->t10[c];
+    const double c3psn = P[P_c3psn];
+    I.c3flag = false;
+    if (round(c3psn) == 1) {
+      I.c3flag = true;
+    } else if (round(c3psn) == 0) {
+      I.c3flag = false;
+    }
+    const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
+    const double act25 = P[P_act25] * 1000.0 / 60.0;
+    double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
+    vcmax25top *= P[P_fnitr];
+    I.vcmax25top = vcmax25top;
+    I.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
+    I.tpu25top = 0.167 * vcmax25top;
+    I.kp25top = 20000.0 * vcmax25top;
+    I.lmr25top = I.c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
+    I.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    I.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    I.tpuse = I.vcmaxse;
+    I.vcmaxha = P[P_vcmaxha];
+    I.jmaxha = P[P_jmaxha];
+    I.tpuha = P[P_tpuha];
+    I.lmrha = P[P_lmrha];
+    I.vcmaxhd = P[P_vcmaxhd];
+    I.jmaxhd = P[P_jmaxhd];
+    I.tpuhd = P[P_tpuhd];
+    I.lmrhd = P[P_lmrhd];
+    I.lmrse = P[P_lmrse];
+    I.kcha = P[P_kcha];
+    I.koha = P[P_koha];
+    I.cpha = P[P_cpha];
+    I.qe = P[P_qe];
+    I.theta_cj = P[P_theta_cj];
+    I.bbbopt = P[P_bbbopt];
+    I.mbbopt = P[P_mbbopt];
+    I.vcmaxc = psn_fth25(I.vcmaxhd, I.vcmaxse);
+    I.jmaxc = psn_fth25(I.jmaxhd, I.jmaxse);
+    I.tpuc = psn_fth25(I.tpuhd, I.tpuse);
+    I.lmrc = psn_fth25(I.lmrhd, I.lmrse);
+    I.cf = forc_pbot / (RGAS * 1.0e-3 * thm) * 1.e06;
+    const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
+    I.kc25 = (404.9 / 1.e06) * forc_pbot;
+    I.ko25 = (278.4 / 1.e03) * forc_pbot;
+    I.cp25 = 0.5 * forc_po2 / sco;
+  }
+  const double dleaf = P[P_dleaf];
+
+  // ================= stability_iteration (:187-452) =================
+  const int nrad = S->nrad[c];
+  const double fwet = S->fwet[c], fdry = S->fdry[c], laisun = S->laisun[c], laisha = S->laisha[c];
+  const double snow_depth = S->snow_depth[c], soilbeta = S->soilbeta[c], frac_h2osfc = S->frac_h2osfc[c];
+  const double frac_sno = S->frac_sno[c], t_h2osfc = S->t_h2osfc[c], sabv = S->sabv[c], h2ocan = S->h2ocan[c];
+  const double htop = S->htop[c];
+  const double vcmaxcintsun = S->vcmaxcintsun[c], vcmaxcintsha = S->vcmaxcintsha[c];
+  double parsun = 0.0, parsha = 0.0, lai_sun_z = 0.0, lai_sha_z = 0.0;
+  if (nrad > 0) {
+    parsun = S->parsun_z[c];
+    parsha = S->parsha_z[c];
+    lai_sun_z = S->laisun_z[c];
+    lai_sha_z = S->laisha_z[c];
+  }
+  // ground-emitted longwave is iteration-invariant (:366-367)
+  const double lw_grnd = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
+                          frac_h2osfc * pow(t_h2osfc, 4.0));
+  const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
+  const bool day = (nrad > 0) && (parsun > 0.0 || parsha > 0.0);
+
+  double qflx_tran_veg = 0.0, qflx_evap_veg = 0.0, eflx_sh_veg = 0.0;
+  double wtg = 0.0, wtl0 = 0.0, wta0 = 0.0, wtal = 0.0, wtgq = 0.0, wtalq = 0.0, wtlq0 = 0.0, wtaq0 = 0.0;
+  double temp1 = 0.0, temp2 = 0.0, temp12m = 0.0, temp22m = 0.0, tlbef = 0.0, dt_veg = 0.0;
+  {
+    bool stop = false;
+    const int itmax = 40, itmin = 2;
+    int itlef = 0, nmozsgn = 0;
+    double del = 0.0, efeb = 0.0, obuold = 0.0;
+#pragma unroll 1
+    while (itlef <= itmax && !stop) {
+      double ustar;
+      friction_profiles(hgt_u, hgt_t, hgt_q, displa, um, obu, z0mv, z0hv, z0qv, ustar, temp1, temp2, temp12m, temp22m);
+      tlbef = t_veg;
+      const double del2 = del;
+      const double ram = 1.0 / (ustar * ustar / um);
+      const double rah0 = 1.0 / (temp1 * ustar);
+      const double raw0 = 1.0 / (temp2 * ustar);
+      const double uaf = um * sqrt(1.0 / (ram * um));
+      const double cf = 0.01 / (sqrt(uaf) * sqrt(dleaf));
+      const double rb = 1.0 / (cf * uaf);
+      const double w = exp(-(elai + esai));
+      const double csoilb = (VKC / (0.13 * pow((z0mg * uaf / 1.5e-5), 0.45)));
+      const double ri = (GRAV * htop * (taf - t_grnd)) / (taf * pow(uaf, 2.0));
+      double csoilcn;
+      if ((taf - t_grnd) > 0.0) {
+        const double ricsoilc = CSOILC / (1.0 + 0.5 * dmin(ri, 10.0));
+        csoilcn = csoilb * w + ricsoilc * (1.0 - w);
+      } else {
+        csoilcn = csoilb * w + CSOILC * (1.0 - w);
+      }
+      const double rah1 = 1.0 / (csoilcn * uaf);
+      const double raw1 = rah1;
+      const double svpts = el;
+      const double eah = forc_pbot * qaf / 0.622;
+
+      // temperature factors of this trip, shared by both phases; the carboxylation / electron-transport /
+      // Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase
+      PsnTemp T;
+      T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
+      T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
+      if (I.c3flag) {
+        T.ft_lmr = psn_ft(t_veg, I.lmrha);
+        T.fth_lmr = psn_fth(t_veg, I.lmrhd, I.lmrse, I.lmrc);
+      } else {
+        T.p2 = pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+        T.e_lmr_c4 = exp(1.3 * (t_veg - (TFRZ + 55.0)));
+      }
+      if (day) {
+        if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
+          T.ft_vcmax = psn_ft(t_veg, I.vcmaxha);
+          T.fth_vcmax = psn_fth(t_veg, I.vcmaxhd, I.vcmaxse, I.vcmaxc);
+        } else {
+          T.e_vc4a = exp(0.2 * ((TFRZ + 15.0) - t_veg));
+          T.e_vc4b = exp(0.3 * (t_veg - (TFRZ + 40.0)));
+        }
+        T.ft_jmax = psn_ft(t_veg, I.jmaxha);
+        T.fth_jmax = psn_fth(t_veg, I.jmaxhd, I.jmaxse, I.jmaxc);
+        T.ft_tpu = psn_ft(t_veg, I.tpuha);
+        T.fth_tpu = psn_fth(t_veg, I.tpuhd, I.tpuse, I.tpuc);
+        T.kc = I.kc25 * psn_ft(t_veg, I.kcha);
+        T.ko = I.ko25 * psn_ft(t_veg, I.koha);
+        T.cp = I.cp25 * psn_ft(t_veg, I.cpha);
+      }
+
+      if (soy) btran = dmin(1.0, btran * 1.25);
+      const double rssun = psn_phase(I, T, nrad, forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, vcmaxcintsun,
+                                     parsun, lai_sun_z, err);
+      if (soy) btran = dmin(1.0, btran * 1.25);
+      const double rssha = psn_phase(I, T, nrad, forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, vcmaxcintsha,
+                                     parsha, lai_sha_z, err);
+
+      const double wta = 1.0 / rah0;
+      const double wtl = (elai + esai) / rb;
+      wtg = 1.0 / rah1;
+      const double wtshi = 1.0 / (wta + wtl + wtg);
+      wtl0 = wtl * wtshi;
+      const double wtg0 = wtg * wtshi;
+      wta0 = wta * wtshi;
+      const double wtga = wta0 + wtg0;
+      wtal = wta0 + wtl0;
+
+      double rppdry;
+      if (fdry > 0.0) {
+        rppdry = fdry * rb * (laisun / (rb + rssun) + laisha / (rb + rssha)) / elai;
+      } else {
+        rppdry = 0.0;
+      }
+      double efpot = forc_rho * wtl * (qsatl - qaf);
+      double rpp;
+      if (efpot > 0.0) {
+        if (btran > 0.0) {
+          qflx_tran_veg = efpot * rppdry;
+          rpp = rppdry + fwet;
+        } else {
+          rpp = fwet;
+          qflx_tran_veg = 0.0;
+        }
+        rpp = dmin(rpp, (qflx_tran_veg + h2ocan / dtime) / efpot);
+      } else {
+        rpp = 1.0;
+        qflx_tran_veg = 0.0;
+      }
+
+      const double wtaq = fvn / raw0;
+      const double wtlq = fvn * (elai + esai) / rb * rpp;
+      const double snow_depth_c = 0.05;
+      const double fsno_dl = snow_depth / snow_depth_c;
+      const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
+      const double rdl = (1.0 - exp(-elai_dl)) / (0.004 * uaf);
+      if (delq < 0.0) {
+        wtgq = fvn / (raw1 + rdl);
+      } else {
+        wtgq = soilbeta * fvn / (raw1 + rdl);
+      }
+      const double wtsqi = 1.0 / (wtaq + wtlq + wtgq);
+      const double wtgq0 = wtgq * wtsqi;
+      wtlq0 = wtlq * wtsqi;
+      wtaq0 = wtaq * wtsqi;
+      const double wtgaq = wtaq0 + wtgq0;
+      wtalq = wtaq0 + wtlq0;
+      const double dc1 = forc_rho * CPAIR * wtl;
+      const double dc2 = HVAP * forc_rho * wtlq;
+      const double efsh = dc1 * (wtga * t_veg - wtg0 * t_grnd - wta0 * thm);
+      double efe = dc2 * (wtgaq * qsatl - wtgq0 * qg - wtaq0 * forc_q);
+
+      double erre = 0.0;
+      if ((efe * efeb) < 0.0) {
+        const double efeold = efe;
+        efe = 0.1 * efeold;
+        erre = efe - efeold;
+      }
+      dt_veg = (sabv + air + bir * pow(t_veg, 4.0) + cir * lw_grnd - efsh - efe) /
+               (-4.0 * bir * pow(t_veg, 3.0) + dc1 * wtga + dc2 * wtgaq * qsatldT);
+      t_veg = tlbef + dt_veg;
+      const double dels = dt_veg;
+      del = fabs(dels);
+      double errv = 0.0;
+      if (del > 1.0) {
+        dt_veg = dels / del;
+        t_veg = tlbef + dt_veg;
+        errv = sabv + air + bir * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) + cir * lw_grnd -
+               (efsh + dc1 * wtga * dt_veg) - (efe + dc2 * wtgaq * qsatldT * dt_veg);
+      }
+      efpot = forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * qg - wtaq0 * forc_q);
+      qflx_evap_veg = rpp * efpot;
+      if (efpot > 0.0 && btran > 0.0) {
+        qflx_tran_veg = efpot * rppdry;
+      } else {
+        qflx_tran_veg = 0.0;
+      }
+      const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - h2ocan / dtime);
+      qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + h2ocan / dtime);
+      eflx_sh_veg = efsh + dc1 * wtga * dt_veg + errv + erre + HVAP * ecidif;
+      qsat(t_veg, forc_pbot, el, deldT, qsatl, qsatldT);
+
+      taf = wtg0 * t_grnd + wta0 * thm + wtl0 * t_veg;
+      qaf = wtlq0 * qsatl + wtgq0 * qg + forc_q * wtaq0;
+      dth = thm - taf;
+      dqh = forc_q - qaf;
+      delq = wtalq * qg - wtlq0 * qsatl - wtaq0 * forc_q;
+      const double tstar = temp1 * dth;
+      const double qstar = temp2 * dqh;
+      const double thvstar = tstar * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * qstar;
+      double zeta = zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * thv);
+      if (zeta >= 0.0) {
+        zeta = dmin(2.0, dmax(zeta, 0.01));
+        um = dmax(ur, 0.1);
+      } else {
+        zeta = dmax(-100.0, dmin(zeta, -0.01));
+        const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / thv), 0.333);
+        um = sqrt(ur * ur + wc * wc);
+      }
+      obu = zldis / zeta;
+      if (obuold * obu < 0.0) nmozsgn += 1;
+      if (nmozsgn >= 4) obu = zldis / (-0.01);
+      obuold = obu;
+
+      itlef += 1;
+      if (itlef > itmin) {
+        const double dele = fabs(efe - efeb);
+        efeb = efe;
+        const double det = dmax(del, del2);
+        if ((det < 0.01) && (dele < 0.1)) stop = true;
+      }
+    }
+  }
+  S->btran[c] = btran;
+  S->t_veg[c] = t_veg;
+  S->qflx_tran_veg[c] = qflx_tran_veg;
+  S->qflx_evap_veg[c] = qflx_evap_veg;
+  S->eflx_sh_veg[c] = eflx_sh_veg;
+
+  // ================= compute_flux (:456-540) =================
+  {
+    const double delt = wtal * t_grnd - wtl0 * t_veg - wta0 * thm;
+    S->eflx_sh_grnd[c] = CPAIR * forc_rho * wtg * delt;
+    const double delt_snow = wtal * t_top - wtl0 * t_veg - wta0 * thm;
+    S->eflx_sh_snow[c] = CPAIR * forc_rho * wtg * delt_snow;
+    const double delt_soil = wtal * t_soi0 - wtl0 * t_veg - wta0 * thm;
+    S->eflx_sh_soil[c] = CPAIR * forc_rho * wtg * delt_soil;
+    const double delt_h2osfc = wtal * t_h2osfc - wtl0 * t_veg - wta0 * thm;
+    S->eflx_sh_h2osfc[c] = CPAIR * forc_rho * wtg * delt_h2osfc;
+    S->qflx_evap_soi[c] = forc_rho * wtgq * delq;
+    const double delq_snow = wtalq * S->qg_snow[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+    S->qflx_ev_snow[c] = forc_rho * wtgq * delq_snow;
+    const double delq_soil = wtalq * S->qg_soil[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+    S->qflx_ev_soil[c] = forc_rho * wtgq * delq_soil;
+    const double delq_h2osfc = wtalq * S->qg_h2osfc[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+    S->qflx_ev_h2osfc[c] = forc_rho * wtgq * delq_h2osfc;
+    const double t_ref2m = thm + temp1 * dth * (1.0 / temp12m - 1.0 / temp1);
+    const double q_ref2m = forc_q + temp2 * dqh * (1.0 / temp22m - 1.0 / temp2);
+    double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
+    qsat(t_ref2m, forc_pbot, e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT);
+    S->t_ref2m[c] = t_ref2m;
+    S->q_ref2m[c] = q_ref2m;
+    S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m) * 100.0);
+    S->dlrad[c] = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
+    S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * forc_lwrad +
+                   emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
+                   emg * (1.0 - emv) * STEBOL * lw_grnd);
+    double cgrnds = 0.0, cgrndl = 0.0;
+    cgrnds += CPAIR * forc_rho * wtg * wtal;
+    cgrndl += forc_rho * wtgq * wtalq * S->dqgdT[c];
+    S->cgrnds[c] = cgrnds;
+    S->cgrndl[c] = cgrndl;
+    S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
+    S->h2ocan[c] = dmax(0.0, h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
+  }
+  if (err) S->err_flags[c] |= err;
+}
+
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_canopy_fluxes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dt);
+}
+
+}  // namespace elmk

@@ -1,0 +1,201 @@
+// k_util.hip - data-movement kernels around the physics: layout conversion, fill, synthetic tiling,
+// error-flag reduction and a copy-bandwidth probe.
+#include "elmk_dev.h"
+#include "elmk_kernels.h"
+
+namespace elmk {
+
+// ---------------------------------------------------------------------------------------------------
+// [column][level] (reference host layout, level fastest) <-> SoA [level][column].
+// A 64-column x nlev tile goes through LDS so both the dense staging side and the SoA side are accessed
+// with consecutive lanes on consecutive addresses.  Tile rows are padded by one element (no bank conflicts
+// on the transposed access).
+// ---------------------------------------------------------------------------------------------------
+constexpr int TCOLS = 64;
+constexpr int MAXLEV = 21;
+
+template <typename T, bool TO_SOA>
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int nlev, int64_t ld,
+                                                   int64_t col0, int64_t n)
+{
+  __shared__ T tile[TCOLS * (MAXLEV + 1)];
+  const int64_t cbase = (int64_t)blockIdx.x * TCOLS;  // first column of this tile, relative to col0
+  const int ncol = (int)((n - cbase) < TCOLS ? (n - cbase) : TCOLS);
+  const int total = ncol * nlev;
+  const int pitch = nlev + 1;
+  if (TO_SOA) {
+    // dense [col][lev] chunk is contiguous: element e -> (col = e / nlev, lev = e % nlev)
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int col = e / nlev, lev = e - col * nlev;
+      tile[col * pitch + lev] = src[cbase * nlev + e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int lev = e / ncol, col = e - lev * ncol;
+      dst[(int64_t)lev * ld + col0 + cbase + col] = tile[col * pitch + lev];
+    }
+  } else {
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int lev = e / ncol, col = e - lev * ncol;
+      tile[col * pitch + lev] = src[(int64_t)lev * ld + col0 + cbase + col];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int col = e / nlev, lev = e - col * nlev;
+      dst[cbase * nlev + e] = tile[col * pitch + lev];
+    }
+  }
+}
+
+template <bool TO_SOA>
+static void transpose_dispatch(const void* src, void* dst, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
+                               hipStream_t st)
+{
+  if (n <= 0) return;
+  const dim3 grid((unsigned)((n + TCOLS - 1) / TCOLS)), block(256);
+  switch (elem) {
+    case 8:
+      hipLaunchKernelGGL((k_transpose<double, TO_SOA>), grid, block, 0, st, (const double*)src, (double*)dst, nlev, ld,
+                         col0, n);
+      break;
+    case 4:
+      hipLaunchKernelGGL((k_transpose<int32_t, TO_SOA>), grid, block, 0, st, (const int32_t*)src, (int32_t*)dst, nlev,
+                         ld, col0, n);
+      break;
+    default:
+      hipLaunchKernelGGL((k_transpose<uint8_t, TO_SOA>), grid, block, 0, st, (const uint8_t*)src, (uint8_t*)dst, nlev,
+                         ld, col0, n);
+      break;
+  }
+}
+
+void launch_cols_to_soa(const void* staging, void* field, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
+                        hipStream_t st)
+{
+  transpose_dispatch<true>(staging, field, elem, nlev, ld, col0, n, st);
+}
+void launch_soa_to_cols(const void* field, void* staging, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
+                        hipStream_t st)
+{
+  transpose_dispatch<false>(field, staging, elem, nlev, ld, col0, n, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill(T* __restrict__ f, int nlev, int64_t ld, int64_t ncols, T v)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  for (int l = 0; l < nlev; l++) f[(int64_t)l * ld + c] = v;
+}
+
+void launch_fill(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, double value, hipStream_t st)
+{
+  if (ncols <= 0) return;
+  const dim3 grid((unsigned)((ncols + 255) / 256)), block(256);
+  if (dtype == ELMK_F64)
+    hipLaunchKernelGGL(k_fill<double>, grid, block, 0, st, (double*)field, nlev, ld, ncols, value);
+  else if (dtype == ELMK_I32)
+    hipLaunchKernelGGL(k_fill<int32_t>, grid, block, 0, st, (int32_t*)field, nlev, ld, ncols, (int32_t)value);
+  else if (dtype == ELMK_U32)
+    hipLaunchKernelGGL(k_fill<uint32_t>, grid, block, 0, st, (uint32_t*)field, nlev, ld, ncols, (uint32_t)value);
+  else
+    hipLaunchKernelGGL(k_fill<uint8_t>, grid, block, 0, st, (uint8_t*)field, nlev, ld, ncols, (uint8_t)value);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic workload: column c >= nbase takes column c % nbase; perturbed fields get a counter-based
+// uniform u in (-1, 1) from splitmix64(seed, field, level, column) - reproducible on any grid shape.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tile(T* __restrict__ f, int nlev, int64_t ld, int64_t ncols, int64_t nbase,
+                                              uint64_t seed, int field_id, int mode, double amp)
+{
+  const int64_t c = nbase + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  const int64_t src = c % nbase;
+  for (int l = 0; l < nlev; l++) {
+    T v = f[(int64_t)l * ld + src];
+    if (mode >= 0) {
+      const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)field_id << 40) ^ ((uint64_t)l << 32) ^ (uint64_t)c));
+      const double u = ((double)(h >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0;
+      const double x = (double)v;
+      v = (T)(mode == 0 ? x * (1.0 + amp * u) : x + amp * u);
+    }
+    f[(int64_t)l * ld + c] = v;
+  }
+}
+
+void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, int64_t nbase, uint64_t seed,
+                 int field_id, int mode, double amp, hipStream_t st)
+{
+  const int64_t n = ncols - nbase;
+  if (n <= 0) return;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == ELMK_F64)
+    hipLaunchKernelGGL(k_tile<double>, grid, block, 0, st, (double*)field, nlev, ld, ncols, nbase, seed, field_id, mode,
+                       amp);
+  else if (dtype == ELMK_I32 || dtype == ELMK_U32)
+    hipLaunchKernelGGL(k_tile<int32_t>, grid, block, 0, st, (int32_t*)field, nlev, ld, ncols, nbase, seed, field_id, -1,
+                       0.0);
+  else
+    hipLaunchKernelGGL(k_tile<uint8_t>, grid, block, 0, st, (uint8_t*)field, nlev, ld, ncols, nbase, seed, field_id, -1,
+                       0.0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// OR of all flag words + first column carrying a fatal bit
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flag_reduce(const uint32_t* __restrict__ flags, int64_t n, uint32_t* or_out,
+                                                     long long* first_bad)
+{
+  uint32_t acc = 0;
+  long long first = 0x7fffffffffffffffll;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t f = flags[c];
+    acc |= f;
+    if ((f & ELMK_ERR_FATAL_MASK) && c < first) first = c;
+  }
+  // wave64 butterfly, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    acc |= __shfl_xor(acc, off, 64);
+    const long long o = __shfl_xor(first, off, 64);
+    first = o < first ? o : first;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (acc) atomicOr(or_out, acc);
+    if (first != 0x7fffffffffffffffll) atomicMin(first_bad, first);
+  }
+}
+
+void launch_flag_reduce(const uint32_t* flags, int64_t n, uint32_t* or_out, long long* first_bad, hipStream_t st)
+{
+  if (n <= 0) return;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_flag_reduce, dim3((unsigned)blocks), dim3(256), 0, st, flags, n, or_out, first_bad);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// streaming copy with the same access shape as the physics kernels (8 bytes per lane): empirical HBM line
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy(const double* __restrict__ src, double* __restrict__ dst, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
+}  // namespace elmk

@@ -1,0 +1,245 @@
+"""ELMState: the host-side mirror of the reference's ELM::ELMState (src/data/elm_state.h:182-225) on top of
+the libelmk context, and the seven physics entry points with the reference's wrapper names.
+
+    S = ELMState(ncols, device=0)
+    S["t_soisno"] = arr            # [ncols, 20], reference layout ([column][level])
+    S.set_land(ltype=1, ctype=1, vtype=12)
+    kokkos_canopy_hydrology(S, dt) # == ELM::kokkos_canopy_hydrology(S, dt) of driver/kokkos
+    out = S["h2osno"]              # download
+
+Everything numerical happens in HIP kernels behind the C ABI; this module only moves arrays and arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+DTYPES = {0: np.float64, 1: np.int32, 2: np.uint8, 3: np.uint32}
+LAYOUT_COL_MAJOR, LAYOUT_SOA = 0, 1
+
+# member order of ELM::PFTDataPSN (src/data/pft_data.h:20-24)
+PSN_FIELDS = (
+    "fnr act25 kcha koha cpha vcmaxha jmaxha tpuha lmrha vcmaxhd jmaxhd tpuhd lmrhd lmrse qe theta_cj "
+    "bbbopt mbbopt c3psn slatop leafcn flnr fnitr dleaf smpso smpsc tc_stress"
+).split()
+ALB_SOURCES = ["rholvis", "rholnir", "rhosvis", "rhosnir", "taulvis", "taulnir", "tausvis", "tausnir", "xl"]
+
+
+def field_table():
+    lib = L.load()
+    out = {}
+    for i in range(lib.elmk_num_fields()):
+        nlev, dt = C.c_int(), C.c_int()
+        lib.elmk_field_info(i, C.byref(nlev), C.byref(dt))
+        out[lib.elmk_field_name(i).decode()] = (i, nlev.value, DTYPES[dt.value])
+    return out
+
+
+def pack_pft(pft):
+    """PFTData::get_pft_psn / get_pft_alb (src/data/pft_data_impl.hh:64-116) for all 25 PFTs -> flat tables."""
+    psn = np.zeros((25, 27))
+    for j, name in enumerate(PSN_FIELDS):
+        v = np.asarray(pft[name], dtype=np.float64).reshape(-1)
+        psn[:, j] = v[0] if name == "tc_stress" else v[:25]
+    alb = np.zeros((25, 9))
+    for j, name in enumerate(ALB_SOURCES):
+        alb[:, j] = np.asarray(pft[name], dtype=np.float64).reshape(-1)[:25]
+    z0mr = np.ascontiguousarray(np.asarray(pft["z0mr"], dtype=np.float64).reshape(-1)[:25])
+    displar = np.ascontiguousarray(np.asarray(pft["displar"], dtype=np.float64).reshape(-1)[:25])
+    return psn, alb, z0mr, displar
+
+
+class ELMState:
+    def __init__(self, ncols, device=0):
+        self.lib = L.load()
+        self.ncols = int(ncols)
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.elmk_create(self.ncols, self.device, C.byref(h))
+        if rc != 0:
+            raise L.ElmkError(f"elmk_create failed ({rc}): {self.lib.elmk_last_error(None).decode()}")
+        self.ctx = h
+        self.fields = field_table()
+        self.scalars = dict(dewmx=0.1, oldfflag=1, dayl=0.0, max_dayl=0.0)
+        self.land = dict(ltype=1, ctype=0, vtype=2, urbpoi=0, lakpoi=0)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.elmk_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise L.ElmkError(f"{what} failed ({rc}): {self.lib.elmk_last_error(self.ctx).decode()}")
+        return rc
+
+    # -- arrays -----------------------------------------------------------------------------------
+    def upload(self, name, arr, col0=0, layout=LAYOUT_COL_MAJOR):
+        fid, nlev, dt = self.fields[name]
+        a = np.ascontiguousarray(arr, dtype=dt)
+        n = a.size // nlev
+        if a.size != n * nlev:
+            raise ValueError(f"{name}: size {a.size} is not a multiple of nlev {nlev}")
+        self._chk(self.lib.elmk_upload(self.ctx, fid, a.ctypes.data, col0, n, layout), f"upload({name})")
+
+    def download(self, name, col0=0, n=None, layout=LAYOUT_COL_MAJOR):
+        fid, nlev, dt = self.fields[name]
+        n = self.ncols - col0 if n is None else n
+        shape = (n,) if nlev == 1 else ((n, nlev) if layout == LAYOUT_COL_MAJOR else (nlev, n))
+        out = np.empty(shape, dtype=dt)
+        self._chk(self.lib.elmk_download(self.ctx, fid, out.ctypes.data, col0, n, layout), f"download({name})")
+        return out
+
+    def __setitem__(self, name, arr):
+        self.upload(name, arr)
+
+    def __getitem__(self, name):
+        return self.download(name)
+
+    def fill(self, name, value):
+        self._chk(self.lib.elmk_fill(self.ctx, self.fields[name][0], float(value)), f"fill({name})")
+
+    def device_ptr(self, name):
+        return self.lib.elmk_device_ptr(self.ctx, self.fields[name][0])
+
+    @property
+    def level_stride(self):
+        return self.lib.elmk_level_stride(self.ctx)
+
+    @property
+    def device_bytes(self):
+        return self.lib.elmk_device_bytes(self.ctx)
+
+    def tile_columns(self, nbase, seed=0x5EEDE1A0, rules=()):
+        """Replicate columns [0, nbase) over the rest of the state; rules = [(field, mode, amp)]."""
+        arr = (L.Perturb * max(len(rules), 1))()
+        for i, (name, mode, amp) in enumerate(rules):
+            arr[i] = L.Perturb(self.fields[name][0], int(mode), float(amp))
+        self._chk(
+            self.lib.elmk_tile_columns(self.ctx, int(nbase), int(seed), len(rules), C.cast(arr, C.c_void_p)),
+            "tile_columns",
+        )
+
+    def snapshot_fields(self, names):
+        ids = (C.c_int * len(names))(*[self.fields[n][0] for n in names])
+        self._chk(self.lib.elmk_snapshot_fields(self.ctx, ids, len(names)), "snapshot_fields")
+
+    def restore_fields(self):
+        self._chk(self.lib.elmk_restore_fields(self.ctx), "restore_fields")
+
+    # -- parameters -------------------------------------------------------------------------------
+    def set_land(self, **kw):
+        self.land.update(kw)
+        l = self.land
+        self._chk(
+            self.lib.elmk_set_land(self.ctx, int(l["ltype"]), int(l["ctype"]), int(l["vtype"]), int(l["urbpoi"]), int(l["lakpoi"])),
+            "set_land",
+        )
+
+    def set_scalars(self, **kw):
+        self.scalars.update(kw)
+        s = self.scalars
+        self._chk(
+            self.lib.elmk_set_scalars(self.ctx, float(s["dewmx"]), int(s["oldfflag"]), float(s["dayl"]), float(s["max_dayl"])),
+            "set_scalars",
+        )
+
+    def set_pft(self, pft):
+        psn, alb, z0mr, displar = pack_pft(pft)
+        self.set_pft_tables(psn, alb, z0mr, displar)
+
+    def set_pft_tables(self, psn, alb, z0mr, displar):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (psn, alb, z0mr, displar)]
+        assert a[0].shape == (25, 27) and a[1].shape == (25, 9) and a[2].shape == (25,) and a[3].shape == (25,)
+        self._chk(self.lib.elmk_set_pft(self.ctx, *[x.ctypes.data for x in a]), "set_pft")
+
+    def set_soilcolor(self, albsat, albdry):
+        a = np.ascontiguousarray(albsat, dtype=np.float64)
+        b = np.ascontiguousarray(albdry, dtype=np.float64)
+        assert a.shape == (20, 2) and b.shape == (20, 2)
+        self._chk(self.lib.elmk_set_soilcolor(self.ctx, a.ctypes.data, b.ctypes.data), "set_soilcolor")
+
+    def set_snicar(self, tables):
+        keep = []
+        t = L.SnicarTables()
+        for name in L.SNICAR_NAMES:
+            a = np.ascontiguousarray(np.asarray(tables[name], dtype=np.float64).reshape(-1))
+            if a.size != L.SNICAR_SIZES[name]:
+                raise ValueError(f"snicar table {name}: {a.size} values, expected {L.SNICAR_SIZES[name]}")
+            keep.append(a)
+            setattr(t, name, a.ctypes.data)
+        self._chk(self.lib.elmk_set_snicar(self.ctx, C.byref(t)), "set_snicar")
+
+    # -- control ----------------------------------------------------------------------------------
+    def sync(self):
+        self._chk(self.lib.elmk_sync(self.ctx), "sync")
+
+    def set_stream(self, hip_stream_handle):
+        self._chk(self.lib.elmk_set_stream(self.ctx, C.c_void_p(hip_stream_handle or 0)), "set_stream")
+
+    def error_summary(self):
+        flags, first = C.c_uint32(), C.c_int64()
+        self._chk(self.lib.elmk_error_summary(self.ctx, C.byref(flags), C.byref(first)), "error_summary")
+        return flags.value, first.value
+
+    def clear_errors(self):
+        self._chk(self.lib.elmk_clear_errors(self.ctx), "clear_errors")
+
+    def profile_timestep7(self, dt, nsteps):
+        ms = (C.c_float * 7)()
+        tot = C.c_float()
+        self._chk(self.lib.elmk_profile_timestep7(self.ctx, float(dt), int(nsteps), ms, C.byref(tot)), "profile_timestep7")
+        return list(ms), tot.value
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=20):
+        g = C.c_double()
+        self._chk(self.lib.elmk_copy_bandwidth(self.ctx, int(nbytes), int(iters), C.byref(g)), "copy_bandwidth")
+        return g.value
+
+
+KERNEL_NAMES = [
+    "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
+    "bareground_fluxes", "canopy_fluxes",
+]
+
+
+# ---- the L3 wrappers, named as in driver/kokkos/*_kokkos.hh ------------------------------------------
+def kokkos_frac_wet(S):
+    S._chk(S.lib.elmk_frac_wet(S.ctx), "frac_wet")
+
+
+def kokkos_albedo_snicar(S):
+    S._chk(S.lib.elmk_albedo_snicar(S.ctx), "albedo_snicar")
+
+
+def kokkos_canopy_hydrology(S, dt):
+    S._chk(S.lib.elmk_canopy_hydrology(S.ctx, float(dt)), "canopy_hydrology")
+
+
+def kokkos_surface_radiation(S):
+    S._chk(S.lib.elmk_surface_radiation(S.ctx), "surface_radiation")
+
+
+def kokkos_canopy_temperature(S):
+    S._chk(S.lib.elmk_canopy_temperature(S.ctx), "canopy_temperature")
+
+
+def kokkos_bareground_fluxes(S):
+    S._chk(S.lib.elmk_bareground_fluxes(S.ctx), "bareground_fluxes")
+
+
+def kokkos_canopy_fluxes(S, dt):
+    S._chk(S.lib.elmk_canopy_fluxes(S.ctx, float(dt)), "canopy_fluxes")
+
+
+def timestep7(S, dt):
+    """The seven calls of ELMInterface::advance (driver/kokkos/elm_kokkos_interface.cc:289-307), in order."""
+    S._chk(S.lib.elmk_timestep7(S.ctx, float(dt)), "timestep7")

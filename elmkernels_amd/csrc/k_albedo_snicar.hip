@@ -5,14 +5,19 @@
 //   snow_snicar::init_timestep :9, snow_aerosol_mie_params :107, snow_radiative_transfer_solver :313,
 //   snow_albedo_radiation_factor :673, run twice (direct, diffuse)   (src/physics/snow_snicar_impl.hh)
 //
-// One thread per column.  The ~210 doubles of per-column scratch that the wrapper allocates as zero-filled
-// Views on every call (albedo_kokkos.cc:19-38) never touch memory here:
+// Two stages.  k_alb_main (one thread per column, coalesced) finishes every column that needs no snow radiative
+// transfer - night columns (init_timestep defaults only) and sunlit snow-free columns (soil albedo + canopy
+// two-stream) - and queues the sunlit snow-covered columns by their number of snow layers.  k_alb_snow<NL> then
+// drains the NL-layer queue with the layer loops fully unrolled for exactly NL layers, so a wave never carries
+// lanes with different layer counts (SNICAR cost is proportional to NL: 10 band-passes x NL Delta-Eddington
+// layer solves with an 8-point Gauss quadrature each).
+// The ~210 doubles of per-column scratch that the wrapper allocates as zero-filled Views on every call
+// (albedo_kokkos.cc:19-38) never touch memory here:
 //   * the Mie/aerosol mixing of a band and the Delta-Eddington adding-doubling solve of the same band are
 //     fused, so g_star/omega_star/tau_star shrink from [5][5] to one band of 5 layers;
 //   * the per-band absorbed fluxes flx_abs_lcl[6][5] are folded into the VIS value and the running
 //     flux-weighted NIR sum as each band finishes (same summation order as :724-741);
-//   * layer loops run over the fixed 5 snow levels with an `i >= snl_top` predicate so every per-layer
-//     array is statically indexed and lives in registers.
+//   * layer loops are compile-time (template NL), every per-layer array is statically indexed and lives in registers.
 // Night columns (coszen <= 0) only write the init_timestep defaults.  Lookup tables (Mie [3][5][1471] x2,
 // BC, aerosol) sit in one 355 KB device buffer that stays L2-resident; the gather index is round(snw_rds)-30.
 #include "elmk_dev.h"
@@ -36,12 +41,13 @@ struct SnowOut {
 
 // One SNICAR pass (flg_slr_in = 1 direct / 2 diffuse) for an active column (coszen > 0, h2osno > min_snw).
 // rds[] = snw_rds_lcl, ice[]/liq[] = h2osoi_*_lcl, mss[i][j] = mss_cnc_aer_in_fdb, snl_top in 0..4.
-template <int FLG>
-__device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, int snl_top, double mu_not,
+template <int FLG, int NL>
+__device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, double mu_not,
                                             const int (&rds)[5], const double (&ice)[5], const double (&liq)[5],
                                             const double (&mss_in)[5][8], const double (&albsoi)[2], SnowOut& out,
                                             uint32_t& err)
 {
+  constexpr int snl_top = 5 - NL;
   const double difgauspt[8] = {0.9894009, 0.9445750, 0.8656312, 0.7554044, 0.6178762, 0.4580168, 0.2816036, 0.0950125};
   const double difgauswt[8] = {0.0271525, 0.0622535, 0.0951585, 0.1246290, 0.1495960, 0.1691565, 0.1826034, 0.1894506};
   const double puny = 1.0e-11;
@@ -320,15 +326,14 @@ __device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, int 
   }
 }
 
-__global__ __launch_bounds__(256) void k_albedo_snicar(const DevState* __restrict__ S)
-{
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= S->ncols) return;
-  const int64_t ld = S->ld;
-  const Land L = S->land;
-  if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
+__device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                           const double coszen, const double elai, const double esai,
+                                           const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
+                                           const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha);
 
-  uint32_t err = 0;
+// per-column body of stage 1; returns the number of snow layers if the column must go through SNICAR, else 0
+__device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L)
+{
   const double coszen = S->coszen[c];
   const double elai = S->elai[c], esai = S->esai[c];
 
@@ -380,12 +385,12 @@ __global__ __launch_bounds__(256) void k_albedo_snicar(const DevState* __restric
     S->fabd_sha_z[c] = 0.0;
     S->fabi_sun_z[c] = 0.0;
     S->fabi_sha_z[c] = 0.0;
-    return;
+    return 0;
   }
+
 
   // =========================== sunlit column ===========================
   const double h2osno = S->h2osno[c];
-  const double frac_sno = S->frac_sno[c];
   const int snl = S->snl[c];
 
   // ---- soil_albedo (:690-754)
@@ -425,66 +430,38 @@ __global__ __launch_bounds__(256) void k_albedo_snicar(const DevState* __restric
     }
   }
 
-  // ---- SNICAR, direct then diffuse (albedo_kokkos.cc:96-301)
+
+  if (h2osno > SN_MIN_SNW) {
+    // snow radiative transfer needed: leave the soil albedos for stage 2 and queue the column
+    LV(albsod, 0) = albsod[0];
+    LV(albsod, 1) = albsod[1];
+    LV(albsoi, 0) = albsoi[0];
+    LV(albsoi, 1) = albsoi[1];
+    return snl == 0 ? 1 : snl;  // snl == 0: one fictitious fresh-snow layer (flg_nosnl, snow_snicar_impl.hh:42-48)
+  }
   SnowOut sd, si;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
     si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
   }
-  if (h2osno > SN_MIN_SNW) {
-    int rds[5] = {0, 0, 0, 0, 0};
-    double ice[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, liq[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    int snl_top;
-    if (snl == 0) {  // fictitious fresh-snow layer (flg_nosnl = 1), snow_snicar_impl.hh:42-48
-      snl_top = NLEVSNO - 1;
-      ice[4] = h2osno;
-      liq[4] = 0.0;
-      rds[4] = (int)round(SNW_RDS_MIN);
-    } else {
-      snl_top = NLEVSNO - snl;
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        // the reference copies all five levels; only i >= snl_top is ever read
-        if (i >= snl_top) {
-          liq[i] = LV(h2osoi_liq, i);
-          ice[i] = LV(h2osoi_ice, i);
-          rds[i] = (int)round(LV(snw_rds, i));
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      if (i >= snl_top && (rds[i] < SN_RDS_MIN_TBL || rds[i] > SN_RDS_MAX_TBL)) {
-        err |= ELMK_ERR_SNICAR_RDS;  // the reference throws (:74-78); clamp so the table gather stays in range
-        rds[i] = rds[i] < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : SN_RDS_MAX_TBL;
-      }
-    }
-    const double mu_not = dmax(coszen, 0.01);
-    // aerosol concentrations (surface_albedo_impl.hh:141-150): OC species 2,3 are ignored
-    double mss[5][8];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
-      if (i >= snl_top) {
-        mss[i][0] = LV(cnc_bcphi, i);
-        mss[i][1] = LV(cnc_bcpho, i);
-        mss[i][4] = LV(cnc_dst1, i);
-        mss[i][5] = LV(cnc_dst2, i);
-        mss[i][6] = LV(cnc_dst3, i);
-        mss[i][7] = LV(cnc_dst4, i);
-      }
-    }
-    snicar_pass<1>(S->snicar, snl_top, mu_not, rds, ice, liq, mss, albsoi, sd, err);
-    snicar_pass<2>(S->snicar, snl_top, mu_not, rds, ice, liq, mss, albsoi, si, err);
-  } else if (h2osno < SN_MIN_SNW && h2osno > 0.0) {  // (:758-761)
+  if (h2osno < SN_MIN_SNW && h2osno > 0.0) {  // snow_snicar_impl.hh:758-761
     sd.alb[0] = si.alb[0] = albsoi[0];
     sd.alb[1] = si.alb[1] = albsoi[1];
   } else {
     sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
   }
+  alb_finish(S, c, ld, L, coszen, elai, esai, S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
+  return 0;
+}
 
+// ground_albedo (:155-167), flux_absorption_factor (:171-211, subgridflag == 1) and two_stream_solver (:323-687,
+// nlevcan == 1) for one sunlit column, given soil albedos and the SNICAR products; stores every output.
+__device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                           const double coszen, const double elai, const double esai,
+                                           const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
+                                           const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha)
+{
   // ---- ground_albedo (:155-167) and flux_absorption_factor (:171-211, subgridflag == 1)
   double albgrd[2], albgri[2];
 #pragma unroll
@@ -679,12 +656,123 @@ __global__ __launch_bounds__(256) void k_albedo_snicar(const DevState* __restric
   S->fabd_sha_z[c] = fabd_sha_z;
   S->fabi_sun_z[c] = fabi_sun_z;
   S->fabi_sha_z[c] = fabi_sha_z;
-  if (err) S->err_flags[c] |= err;
+}
+
+// =====================================================================================================
+// stage 1: every column
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_alb_main(const DevState* __restrict__ S)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
+  const bool inside = c < S->ncols;
+  int nl = 0;  // > 0: column needs the snow radiative-transfer stage with nl layers
+  if (inside) nl = alb_main_column(S, c, ld, L);
+  list_append(S->lists + (int64_t)LIST_ALB_1 * ld, &S->counters[LIST_ALB_1], nl == 1, (int32_t)c);
+  list_append(S->lists + (int64_t)LIST_ALB_2 * ld, &S->counters[LIST_ALB_2], nl == 2, (int32_t)c);
+  list_append(S->lists + (int64_t)LIST_ALB_3 * ld, &S->counters[LIST_ALB_3], nl == 3, (int32_t)c);
+  list_append(S->lists + (int64_t)LIST_ALB_4 * ld, &S->counters[LIST_ALB_4], nl == 4, (int32_t)c);
+  list_append(S->lists + (int64_t)LIST_ALB_5 * ld, &S->counters[LIST_ALB_5], nl == 5, (int32_t)c);
+}
+
+// =====================================================================================================
+// stage 2: sunlit snow-covered columns with exactly NL (possibly fictitious) snow layers
+// =====================================================================================================
+template <int NL>
+__global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S)
+{
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  const uint32_t count = S->counters[LIST_ALB_1 + NL - 1];
+  const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_1 + NL - 1) * ld;
+  constexpr int snl_top = NLEVSNO - NL;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
+    const int64_t c = list[q];
+    uint32_t err = 0;
+    const double coszen = S->coszen[c];
+    const double elai = S->elai[c], esai = S->esai[c];
+    const double h2osno = S->h2osno[c];
+    const int snl = S->snl[c];
+    const double albsod[2] = {LV(albsod, 0), LV(albsod, 1)};
+    const double albsoi[2] = {LV(albsoi, 0), LV(albsoi, 1)};
+    // init_timestep values of the leaf-to-canopy scaling coefficients (overwritten by two_stream where vegetated)
+    double vcmaxcintsun = 0.0;
+    double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
+    if (elai > 0.0) {
+      vcmaxcintsha /= elai;
+    } else {
+      vcmaxcintsha = 0.0;
+    }
+
+    int rds[5] = {0, 0, 0, 0, 0};
+    double ice[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, liq[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (snl == 0) {  // only possible for NL == 1
+      ice[4] = h2osno;
+      liq[4] = 0.0;
+      rds[4] = (int)round(SNW_RDS_MIN);
+    } else {
+#pragma unroll
+      for (int i = snl_top; i < 5; i++) {  // the reference copies all five levels; only i >= snl_top is ever read
+        liq[i] = LV(h2osoi_liq, i);
+        ice[i] = LV(h2osoi_ice, i);
+        rds[i] = (int)round(LV(snw_rds, i));
+      }
+    }
+#pragma unroll
+    for (int i = snl_top; i < 5; i++) {
+      if (rds[i] < SN_RDS_MIN_TBL || rds[i] > SN_RDS_MAX_TBL) {
+        err |= ELMK_ERR_SNICAR_RDS;  // the reference throws (:74-78); clamp so the table gather stays in range
+        rds[i] = rds[i] < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : SN_RDS_MAX_TBL;
+      }
+    }
+    const double mu_not = dmax(coszen, 0.01);
+    // aerosol concentrations (surface_albedo_impl.hh:141-150): OC species 2,3 are ignored
+    double mss[5][8];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int i = snl_top; i < 5; i++) {
+      mss[i][0] = LV(cnc_bcphi, i);
+      mss[i][1] = LV(cnc_bcpho, i);
+      mss[i][4] = LV(cnc_dst1, i);
+      mss[i][5] = LV(cnc_dst2, i);
+      mss[i][6] = LV(cnc_dst3, i);
+      mss[i][7] = LV(cnc_dst4, i);
+    }
+    SnowOut sd, si;
+    snicar_pass<1, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, sd, err);
+    snicar_pass<2, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, si, err);
+    alb_finish(S, c, ld, L, coszen, elai, esai, S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
+    if (err) S->err_flags[c] |= err;
+  }
+}
+
+__global__ void k_alb_reset(const DevState* __restrict__ S)
+{
+  if (threadIdx.x < 5) {
+    S->counters[LIST_ALB_1 + threadIdx.x] = 0u;
+    S->counters[NLISTS + LIST_ALB_1 + threadIdx.x] = 0u;
+  }
 }
 
 void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_albedo_snicar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S);
+  if (n <= 0) return;
+  const dim3 block(256);
+  const unsigned full = (unsigned)((n + 255) / 256);
+  const unsigned capped = full < 2048u ? full : 2048u;  // queue kernels are grid-stride over a device-side count
+  hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
+  hipLaunchKernelGGL(k_alb_main, dim3(full), block, 0, st, S);
+  hipLaunchKernelGGL(k_alb_snow<5>, dim3(capped), block, 0, st, S);  // longest work first
+  hipLaunchKernelGGL(k_alb_snow<4>, dim3(capped), block, 0, st, S);
+  hipLaunchKernelGGL(k_alb_snow<3>, dim3(capped), block, 0, st, S);
+  hipLaunchKernelGGL(k_alb_snow<2>, dim3(capped), block, 0, st, S);
+  hipLaunchKernelGGL(k_alb_snow<1>, dim3(capped), block, 0, st, S);
 }
 
 }  // namespace elmk

@@ -108,6 +108,7 @@ enum : int {
   LIST_CF_DAY = 0,   // vegetated columns with PAR > 0 on either leaf class
   LIST_CF_NIGHT,     // vegetated columns without PAR
   LIST_BG,           // bare-ground columns
+  LIST_ALB_0,        // sunlit snow-free columns (soil albedo + canopy two-stream only)
   LIST_ALB_1,        // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
   LIST_ALB_2,
   LIST_ALB_3,
@@ -116,17 +117,43 @@ enum : int {
   NLISTS
 };
 
-// wave64-aggregated append of column c to a list: one atomic per wave (called by all lanes; pred selects)
-__device__ __forceinline__ void list_append(int32_t* __restrict__ list, uint32_t* __restrict__ count, bool pred, int32_t c)
+// Queue counters live one per 128-byte line (same-line atomics serialise in one L2 channel):
+// length of list k at counters[k * CPAD], queue head of list k at counters[(NLISTS + k) * CPAD].
+constexpr int CPAD = 32;
+#define ELMK_LIST_COUNT(S, k) ((S)->counters[(k)*CPAD])
+#define ELMK_LIST_HEAD(S, k) ((S)->counters[(NLISTS + (k)) * CPAD])
+
+// Workgroup-aggregated classification append: every thread of the (256-thread) workgroup calls this with its class
+// cls in [0, NCLS) or -1; column c goes to list first_list + cls.  One global atomic per class per workgroup;
+// order inside a list follows (workgroup arrival, wave, lane).  All threads of the workgroup must call it.
+template <int NCLS>
+__device__ __forceinline__ void block_classify_append(int32_t* __restrict__ lists, int64_t ld, uint32_t* __restrict__ counters,
+                                                      int first_list, int cls, int32_t c)
 {
-  const unsigned long long m = __ballot(pred);
-  if (m == 0ull) return;
+  __shared__ uint32_t s_cnt[NCLS];
+  __shared__ uint32_t s_base[NCLS];
+  if (threadIdx.x < NCLS) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-  base = __shfl(base, leader, 64);
-  if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+  uint32_t my_off = 0u;
+#pragma unroll
+  for (int k = 0; k < NCLS; k++) {
+    const unsigned long long m = __ballot(cls == k);
+    if (m != 0ull) {
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t off = 0u;
+      if (lane == leader) off = atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+      off = __shfl(off, leader, 64);
+      if (cls == k) my_off = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NCLS) {
+    const uint32_t n = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] = n ? atomicAdd(&counters[(first_list + threadIdx.x) * CPAD], n) : 0u;
+  }
+  __syncthreads();
+  if (cls >= 0) lists[(int64_t)(first_list + cls) * ld + s_base[cls] + my_off] = c;
 }
 
 // Everything a kernel needs, resident in device memory (kernels get one pointer; all loads from this

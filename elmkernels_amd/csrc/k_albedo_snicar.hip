@@ -335,7 +335,7 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
 __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L)
 {
   const double coszen = S->coszen[c];
-  const double elai = S->elai[c], esai = S->esai[c];
+  const double elai = S->elai[c];
 
   // ---- canopy_layer_lai (:215-319), nlevcan == 1: one big-leaf layer
   S->nrad[c] = 1;
@@ -385,7 +385,7 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
     S->fabd_sha_z[c] = 0.0;
     S->fabi_sun_z[c] = 0.0;
     S->fabi_sha_z[c] = 0.0;
-    return 0;
+    return -1;  // night column: complete
   }
 
 
@@ -431,27 +431,14 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
   }
 
 
-  if (h2osno > SN_MIN_SNW) {
-    // snow radiative transfer needed: leave the soil albedos for stage 2 and queue the column
-    LV(albsod, 0) = albsod[0];
-    LV(albsod, 1) = albsod[1];
-    LV(albsoi, 0) = albsoi[0];
-    LV(albsoi, 1) = albsoi[1];
-    return snl == 0 ? 1 : snl;  // snl == 0: one fictitious fresh-snow layer (flg_nosnl, snow_snicar_impl.hh:42-48)
-  }
-  SnowOut sd, si;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
-    si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
-  }
-  if (h2osno < SN_MIN_SNW && h2osno > 0.0) {  // snow_snicar_impl.hh:758-761
-    sd.alb[0] = si.alb[0] = albsoi[0];
-    sd.alb[1] = si.alb[1] = albsoi[1];
-  } else {
-    sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
-  }
-  alb_finish(S, c, ld, L, coszen, elai, esai, S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
+  // sunlit: leave the soil albedos for stage 2 and queue the column by its snow-layer count
+  LV(albsod, 0) = albsod[0];
+  LV(albsod, 1) = albsod[1];
+  LV(albsoi, 0) = albsoi[0];
+  LV(albsoi, 1) = albsoi[1];
+  (void)vcmaxcintsun;
+  (void)vcmaxcintsha;
+  if (h2osno > SN_MIN_SNW) return snl == 0 ? 1 : snl;  // snl == 0: one fictitious fresh-snow layer (flg_nosnl, :42-48)
   return 0;
 }
 
@@ -668,13 +655,9 @@ __global__ __launch_bounds__(256) void k_alb_main(const DevState* __restrict__ S
   const Land L = S->land;
   if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
   const bool inside = c < S->ncols;
-  int nl = 0;  // > 0: column needs the snow radiative-transfer stage with nl layers
+  int nl = -1;  // >= 0: sunlit column, goes to stage 2 with nl snow layers (0: snow-free)
   if (inside) nl = alb_main_column(S, c, ld, L);
-  list_append(S->lists + (int64_t)LIST_ALB_1 * ld, &S->counters[LIST_ALB_1], nl == 1, (int32_t)c);
-  list_append(S->lists + (int64_t)LIST_ALB_2 * ld, &S->counters[LIST_ALB_2], nl == 2, (int32_t)c);
-  list_append(S->lists + (int64_t)LIST_ALB_3 * ld, &S->counters[LIST_ALB_3], nl == 3, (int32_t)c);
-  list_append(S->lists + (int64_t)LIST_ALB_4 * ld, &S->counters[LIST_ALB_4], nl == 4, (int32_t)c);
-  list_append(S->lists + (int64_t)LIST_ALB_5 * ld, &S->counters[LIST_ALB_5], nl == 5, (int32_t)c);
+  block_classify_append<6>(S->lists, ld, S->counters, LIST_ALB_0, nl, (int32_t)c);
 }
 
 // =====================================================================================================
@@ -685,8 +668,8 @@ __global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S
 {
   const int64_t ld = S->ld;
   const Land L = S->land;
-  const uint32_t count = S->counters[LIST_ALB_1 + NL - 1];
-  const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_1 + NL - 1) * ld;
+  const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
+  const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
   constexpr int snl_top = NLEVSNO - NL;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
     const int64_t c = list[q];
@@ -706,6 +689,22 @@ __global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S
       vcmaxcintsha = 0.0;
     }
 
+    SnowOut sd, si;
+    if constexpr (NL == 0) {
+      // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
+        si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
+      }
+      if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
+        sd.alb[0] = si.alb[0] = albsoi[0];
+        sd.alb[1] = si.alb[1] = albsoi[1];
+      } else {
+        sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
+      }
+      (void)snl;
+    } else {
     int rds[5] = {0, 0, 0, 0, 0};
     double ice[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, liq[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (snl == 0) {  // only possible for NL == 1
@@ -744,9 +743,9 @@ __global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S
       mss[i][6] = LV(cnc_dst3, i);
       mss[i][7] = LV(cnc_dst4, i);
     }
-    SnowOut sd, si;
     snicar_pass<1, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, sd, err);
     snicar_pass<2, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, si, err);
+    }
     alb_finish(S, c, ld, L, coszen, elai, esai, S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
     if (err) S->err_flags[c] |= err;
   }
@@ -754,9 +753,9 @@ __global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S
 
 __global__ void k_alb_reset(const DevState* __restrict__ S)
 {
-  if (threadIdx.x < 5) {
-    S->counters[LIST_ALB_1 + threadIdx.x] = 0u;
-    S->counters[NLISTS + LIST_ALB_1 + threadIdx.x] = 0u;
+  if (threadIdx.x < 6) {
+    ELMK_LIST_COUNT(S, LIST_ALB_0 + threadIdx.x) = 0u;
+    ELMK_LIST_HEAD(S, LIST_ALB_0 + threadIdx.x) = 0u;
   }
 }
 
@@ -773,6 +772,7 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st)
   hipLaunchKernelGGL(k_alb_snow<3>, dim3(capped), block, 0, st, S);
   hipLaunchKernelGGL(k_alb_snow<2>, dim3(capped), block, 0, st, S);
   hipLaunchKernelGGL(k_alb_snow<1>, dim3(capped), block, 0, st, S);
+  hipLaunchKernelGGL(k_alb_snow<0>, dim3(capped), block, 0, st, S);
 }
 
 }  // namespace elmk

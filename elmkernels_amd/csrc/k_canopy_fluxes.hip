@@ -441,8 +441,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 
     day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
   }
-  list_append(S->lists + (int64_t)LIST_CF_DAY * ld, &S->counters[LIST_CF_DAY], veg && day, (int32_t)c);
-  list_append(S->lists + (int64_t)LIST_CF_NIGHT * ld, &S->counters[LIST_CF_NIGHT], veg && !day, (int32_t)c);
+  block_classify_append<2>(S->lists, ld, S->counters, LIST_CF_DAY, veg ? (day ? 0 : 1) : -1, (int32_t)c);
 }
 
 // =====================================================================================================
@@ -508,9 +507,9 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         const unsigned long long m = __ballot(take);
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&S->counters[NLISTS + which], (uint32_t)__popcll(m));
+        if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, which), (uint32_t)__popcll(m));
         base = __shfl(base, leader, 64);
-        const uint32_t count = S->counters[which];
+        const uint32_t count = ELMK_LIST_COUNT(S, which);
         const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (take && mine < count) c = S->lists[(int64_t)which * ld + mine];
         if (base + (uint32_t)__popcll(m) > count) dry = true;
@@ -869,10 +868,10 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 __global__ void k_cf_reset(const DevState* __restrict__ S)
 {
   if (threadIdx.x == 0) {
-    S->counters[LIST_CF_DAY] = 0u;
-    S->counters[LIST_CF_NIGHT] = 0u;
-    S->counters[NLISTS + LIST_CF_DAY] = 0u;
-    S->counters[NLISTS + LIST_CF_NIGHT] = 0u;
+    ELMK_LIST_COUNT(S, LIST_CF_DAY) = 0u;
+    ELMK_LIST_COUNT(S, LIST_CF_NIGHT) = 0u;
+    ELMK_LIST_HEAD(S, LIST_CF_DAY) = 0u;
+    ELMK_LIST_HEAD(S, LIST_CF_NIGHT) = 0u;
   }
 }
 

@@ -626,17 +626,38 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
 //   initialize_flux :7, stability_iteration :30, compute_flux :82 of bareground_fluxes_impl.hh
 //   active only where frac_veg_nosno == 0; everywhere else just cgrnd/cgrnds/cgrndl = 0
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_bareground_fluxes(const DevState* __restrict__ S)
+// stage 1 (every column, streaming): compute_flux's unconditional cgrnd reset (:97-102) and the queue of bare columns
+__global__ __launch_bounds__(256) void k_bg_main(const DevState* __restrict__ S)
 {
-  COL_GUARD();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const Land L = S->land;
-  if (!L.lakpoi) {
-    // compute_flux's unconditional reset (:97-102); overwritten below for bare columns
+  if (L.lakpoi) return;
+  const bool inside = c < S->ncols;
+  if (inside) {
     S->cgrnd[c] = 0.0;
     S->cgrnds[c] = 0.0;
     S->cgrndl[c] = 0.0;
   }
-  if (L.lakpoi || L.urbpoi || S->frac_veg_nosno[c] != 0) return;
+  const bool bare = inside && !L.urbpoi && S->frac_veg_nosno[c] == 0;
+  block_classify_append<1>(S->lists, S->ld, S->counters, LIST_BG, bare ? 0 : -1, (int32_t)c);
+}
+
+__global__ void k_bg_reset(const DevState* __restrict__ S)
+{
+  if (threadIdx.x == 0) {
+    ELMK_LIST_COUNT(S, LIST_BG) = 0u;
+    ELMK_LIST_HEAD(S, LIST_BG) = 0u;
+  }
+}
+
+// stage 2 (bare columns only, from the queue): the Monin-Obukhov iteration and the fluxes
+__global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
+{
+  const int64_t ld = S->ld;
+  const uint32_t count = ELMK_LIST_COUNT(S, LIST_BG);
+  const int32_t* __restrict__ list = S->lists + (int64_t)LIST_BG * ld;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
+  const int64_t c = list[q];
 
   const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c], forc_th = S->forc_thbot[c];
   const double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
@@ -719,6 +740,7 @@ __global__ __launch_bounds__(256) void k_bareground_fluxes(const DevState* __res
   S->t_ref2m[c] = t_ref2m;
   S->q_ref2m[c] = q_ref2m;
   S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m * 100.0));
+  }
 }
 
 // ---- host launchers ---------------------------------------------------------------------------------
@@ -742,7 +764,11 @@ void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st)
 }
 void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_bareground_fluxes, grid_for(n), dim3(256), 0, st, S);
+  if (n <= 0) return;
+  const unsigned full = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_bg_reset, dim3(1), dim3(64), 0, st, S);
+  hipLaunchKernelGGL(k_bg_main, dim3(full), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S);
 }
 
 }  // namespace elmk

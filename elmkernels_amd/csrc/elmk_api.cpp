@@ -164,7 +164,9 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
   const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
   const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + align_up((size_t)2 * NLISTS * CPAD * 4, 256);
+  const size_t cnt_bytes = align_up((size_t)2 * NLISTS * CPAD * 4, 256);
+  const size_t hint_bytes = align_up((size_t)ctx->ld * 4, 256);
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -190,6 +192,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.wk = (double*)ctx->scratch;
   h.lists = (int32_t*)(ctx->scratch + wk_bytes);
   h.counters = (uint32_t*)(ctx->scratch + wk_bytes + list_bytes);
+  h.cf_niter = (int32_t*)(ctx->scratch + wk_bytes + list_bytes + cnt_bytes);
   {
     int f = 0;
 #define ELMK_FIELD(name, T, nlev) h.name = (ctype_of<ELMK_##T>::type*)ctx->fptr[f++];

@@ -105,8 +105,13 @@ enum : int {
   WK_N
 };
 enum : int {
-  LIST_CF_DAY = 0,   // vegetated columns with PAR > 0 on either leaf class
-  LIST_CF_NIGHT,     // vegetated columns without PAR
+  // canopy_fluxes: vegetated columns, by PAR (day: a leaf class absorbs PAR) and by the trip count of the previous
+  // call (long first: longest-processing-time-first keeps the tail of the persistent kernel short).  The four lists
+  // are drained in this order as one queue (head counter of LIST_CF_DAY_LONG).
+  LIST_CF_DAY_LONG = 0,
+  LIST_CF_NIGHT_LONG,
+  LIST_CF_DAY,
+  LIST_CF_NIGHT,
   LIST_BG,           // bare-ground columns
   LIST_ALB_0,        // sunlit snow-free columns (soil albedo + canopy two-stream only)
   LIST_ALB_1,        // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
@@ -173,7 +178,8 @@ struct DevState {
   // per-call scratch owned by the context (never part of the state contract):
   double* wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
   int32_t* lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
-  uint32_t* counters;  // [0, NLISTS): list lengths;  [NLISTS, 2*NLISTS): queue heads
+  uint32_t* counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
+  int32_t* cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
 #define ELMK_FIELD(name, T, nlev) ctype_of<ELMK_##T>::type* name;
 #include "elmk_fields.def"
 #undef ELMK_FIELD

@@ -24,6 +24,8 @@ namespace elmk {
 
 #define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
 
+constexpr int CF_LONG_TRIPS = 14;  // previous-call trip count from which a column is scheduled first
+
 // photosynthesis_impl.hh:623-635
 __device__ __forceinline__ double psn_ft(double tl, double ha)
 {
@@ -441,7 +443,10 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 
     day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
   }
-  block_classify_append<2>(S->lists, ld, S->counters, LIST_CF_DAY, veg ? (day ? 0 : 1) : -1, (int32_t)c);
+  // scheduling class: columns that needed many trips last time go to the front of the queue
+  int cls = -1;
+  if (veg) cls = ((S->cf_niter[c] >= CF_LONG_TRIPS) ? 0 : 2) + (day ? 0 : 1);
+  block_classify_append<4>(S->lists, ld, S->counters, LIST_CF_DAY_LONG, cls, (int32_t)c);
 }
 
 // =====================================================================================================
@@ -470,9 +475,12 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   const double dl = S->dayl, mdl = S->max_dayl;
   const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
 
-  int which = LIST_CF_DAY;  // wave-uniform: queue currently being drained
-  bool dry = false;         // wave-uniform: the current queue has been seen empty
-  bool exhausted = false;   // wave-uniform: both queues empty
+  // the four work lists form one queue; their lengths are final (k_cf_init has completed)
+  const uint32_t n0 = ELMK_LIST_COUNT(S, LIST_CF_DAY_LONG);
+  const uint32_t n1 = n0 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT_LONG);
+  const uint32_t n2 = n1 + ELMK_LIST_COUNT(S, LIST_CF_DAY);
+  const uint32_t n3 = n2 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT);
+  bool exhausted = false;   // wave-uniform: the queue is empty
   int64_t c = -1;           // column owned by this lane (-1: idle)
 
   CfLane in;
@@ -489,31 +497,33 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 
   for (;;) {
     // ---------------- refill ----------------
-    // Idle lanes are refilled in batches (>= CF_REFILL_MIN of them, which includes the all-idle wave).  A wave only
-    // moves from the day queue to the night queue once it holds no day column any more, so its lanes always run
-    // the same photosynthesis path.
+    // Idle lanes are refilled in batches (>= CF_REFILL_MIN of them, which includes the all-idle wave) with one
+    // wave-aggregated atomic on the queue head.
     const int nidle = __popcll(__ballot(c < 0));
     if (!exhausted && nidle >= CF_REFILL_MIN) {
-      if (dry && nidle == 64) {
-        if (which == LIST_CF_DAY) {
-          which = LIST_CF_NIGHT;
-          dry = false;
-        } else {
-          exhausted = true;
+      const bool take = (c < 0);
+      const unsigned long long m = __ballot(take);
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_DAY_LONG), (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (take && mine < n3) {
+        int li = 3;
+        uint32_t off = mine - n2;
+        if (mine < n0) {
+          li = 0;
+          off = mine;
+        } else if (mine < n1) {
+          li = 1;
+          off = mine - n0;
+        } else if (mine < n2) {
+          li = 2;
+          off = mine - n1;
         }
+        c = S->lists[(int64_t)(LIST_CF_DAY_LONG + li) * ld + off];
       }
-      if (!exhausted && !dry) {
-        const bool take = (c < 0);
-        const unsigned long long m = __ballot(take);
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, which), (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        const uint32_t count = ELMK_LIST_COUNT(S, which);
-        const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (take && mine < count) c = S->lists[(int64_t)which * ld + mine];
-        if (base + (uint32_t)__popcll(m) > count) dry = true;
-      }
+      if (base + (uint32_t)__popcll(m) >= n3) exhausted = true;
     }
     // lanes that just received a column (P not set yet) gather its inputs and set up the iteration
     if (c >= 0 && P == nullptr) {
@@ -858,6 +868,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
         S->h2ocan[c] = dmax(0.0, in.h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
         if (err) S->err_flags[c] |= err;
+        S->cf_niter[c] = itlef;
         c = -1;
         P = nullptr;
       }
@@ -868,10 +879,10 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 __global__ void k_cf_reset(const DevState* __restrict__ S)
 {
   if (threadIdx.x == 0) {
-    ELMK_LIST_COUNT(S, LIST_CF_DAY) = 0u;
-    ELMK_LIST_COUNT(S, LIST_CF_NIGHT) = 0u;
-    ELMK_LIST_HEAD(S, LIST_CF_DAY) = 0u;
-    ELMK_LIST_HEAD(S, LIST_CF_NIGHT) = 0u;
+    for (int k = LIST_CF_DAY_LONG; k <= LIST_CF_NIGHT; k++) {
+      ELMK_LIST_COUNT(S, k) = 0u;
+      ELMK_LIST_HEAD(S, k) = 0u;
+    }
   }
 }
 

@@ -62,7 +62,7 @@ def build_state(ncols, device, tier, seed):
     return D, (cols, scal, soil)
 
 
-def cpu_baseline(host_state, budget_s=20.0):
+def cpu_baseline(host_state, budget_s=15.0):
     """The oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP) on the
     host cores, on a bounded sample of the same workload."""
     from tests import helpers as H
@@ -87,12 +87,38 @@ def cpu_baseline(host_state, budget_s=20.0):
         S.timestep7(1800.0)
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 200:
+        if el > budget_s or steps >= 5000:
             break
     return {
         "value": n * steps / el, "unit": "gridcell-timesteps/s", "cores": int(threads), "kind": "port",
         "sample": f"{n} columns x {steps} timesteps of the same tier, oracle/libelmoracle.so (gcc -O2 -fopenmp), {el:.1f} s",
     }
+
+
+# HIP kernels behind each wrapper (names as rocprofv3 reports them)
+SUB_KERNELS = {
+    "frac_wet": ["elmk::k_frac_wet"],
+    "albedo_snicar": ["elmk::k_alb_main"] + [f"elmk::k_alb_snow<{i}>" for i in range(6)],
+    "canopy_hydrology": ["elmk::k_canopy_hydrology"],
+    "surface_radiation": ["elmk::k_surface_radiation"],
+    "canopy_temperature": ["elmk::k_canopy_temperature"],
+    "bareground_fluxes": ["elmk::k_bg_main", "elmk::k_bg_flux"],
+    "canopy_fluxes": ["elmk::k_cf_init", "elmk::k_cf_iterate"],
+}
+
+
+def pmc_traffic(wrapper, args):
+    """HBM bytes per launch of the wrapper's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    calibrated on gfx950, WRITE_SIZE as is; profiles/r01_hbm_traffic_pmc.json).  The counters cannot be read from
+    inside this process, so the number is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    if args.cols != 1_000_000 or args.tier != "B" or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    try:
+        return float(sum(k[name]["hbm_bytes_per_launch"] for name in SUB_KERNELS[wrapper]))
+    except KeyError:
+        return None
 
 
 def main():
@@ -197,12 +223,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_" + dom[0],
+                "kernel": " + ".join(n.replace("elmk::", "") for n in SUB_KERNELS[dom[0]]),
                 "achieved": dom_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": dom_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(dom[0], args),
                 "bytes_per_column": ALGO_BYTES[dom[0]],
                 "avg_launch_ms": dom[1],
             },

@@ -157,7 +157,7 @@ void *elmk_device_ptr(elmk_ctx *ctx, int field);      /* SoA base: element (lev,
  * perturbations (synthetic-workload generator for the benchmark) */
 int elmk_tile_columns(elmk_ctx *ctx, int64_t nbase, uint64_t seed, int nrules, const elmk_perturb *rules);
 /* Keep a device-side copy of the listed fields as they are now (replaces any earlier snapshot), and copy
- * them back later (asynchronous device-to-device copies on the context's stream).  A driver uses this for
+ * them back later (a streaming copy kernel on the context's stream).  A driver uses this for
  * what the rest of the model would do between two calls of the hot path - e.g. the reference resets the
  * forcing heights every step (atm_physics_impl.hh:197-203) and other components move t_veg; the benchmark
  * uses it so that every timed step starts from the same, unconverged canopy state. */
@@ -189,7 +189,8 @@ int elmk_clear_errors(elmk_ctx *ctx);
 /* run `nsteps` timesteps with HIP events between the seven launches on the context's stream;
  * ms_per_kernel[7] (frac_wet, albedo_snicar, canopy_hydrology, surface_radiation, canopy_temperature,
  * bareground_fluxes, canopy_fluxes) receives the mean device time of each launch, *ms_total the mean
- * time of one whole timestep (first event to last). */
+ * time of one whole timestep (first event to last).  If a snapshot exists (elmk_snapshot_fields) it is
+ * restored before every step, outside the event brackets, so each profiled step does the same work. */
 int elmk_profile_timestep7(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_kernel, float *ms_total);
 /* device-to-device copy bandwidth probe (read+write bytes / s) on this context's device, used as the
  * empirical HBM line next to the 8 TB/s datasheet peak */

@@ -1,0 +1,116 @@
+"""CPU-only checks of everything around the HIP kernels: the C-ABI library loads and exports every symbol that
+include/elmk.h declares, schema consistency between the product and the oracle, the column decomposition, the
+synthetic-state generator, and the fixture converter.  No compute call is made (there is no GPU here, and the
+product has no CPU path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import elmkernels_amd as E
+from elmkernels_amd import _lib, decomp, synth
+from elmkernels_amd import state as st
+from oracle import oracle as O
+from tests import fixtures as F
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "elmk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(elmk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"libelmk.so lacks {name} declared in include/elmk.h"
+    # and the ctypes table covers the whole header (no entry point is bound by guesswork)
+    assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a HIP device the product refuses to create a context (it must never compute on the CPU)."""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.elmk_create(16, 0, ctypes.byref(h))
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert rc == -2 and not h.value
+    assert b"no CPU fallback" in lib.elmk_last_error(None)
+    with pytest.raises(_lib.ElmkError):
+        E.ELMState(16)
+
+
+def test_field_schema_matches_reference_state_and_oracle():
+    ft = st.field_table()
+    oracle_ft = H.field_table_from_oracle()
+    assert set(ft) - {"err_flags"} == set(oracle_ft)
+    for name, (_, nlev, dt) in oracle_ft.items():
+        assert ft[name][1] == nlev and np.dtype(ft[name][2]) == np.dtype(dt), name
+    # extents of ELMStateViews (src/data/elm_state_impl.hh:48-364)
+    assert ft["t_soisno"][1] == 20 and ft["zisoi"][1] == 21 and ft["sabg_lyr"][1] == 6 and ft["watsat"][1] == 15
+    assert ft["snw_rds"][1] == 5 and ft["albd"][1] == 2 and ft["veg_active"][2] == np.uint8 and ft["snl"][2] == np.int32
+    lib = _lib.load()
+    assert lib.elmk_field_id(b"t_soisno") == ft["t_soisno"][0] and lib.elmk_field_id(b"nope") == -1
+    assert lib.elmk_field_name(ft["cgrnd"][0]) == b"cgrnd"
+
+
+def test_block_decomposition_matches_reference_rule():
+    """create_domain_decomposition_1D (src/utils/utils.cc:27-44): first N % P ranks own one extra column."""
+    for n, p in ((10, 3), (80_000_000, 8), (7, 8), (0, 4), (1_000_001, 2)):
+        r = decomp.all_ranges(n, p)
+        assert sum(c for _, c in r) == n
+        assert r[0][0] == 0 and all(r[i][0] + r[i][1] == r[i + 1][0] for i in range(p - 1))
+        sizes = [c for _, c in r]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert decomp.block_range(10, 3, 0) == (0, 4) and decomp.block_range(10, 3, 2) == (7, 3)
+    with pytest.raises(ValueError):
+        decomp.block_range(10, 0, 0)
+
+
+def test_synthetic_states_are_deterministic_and_cover_the_branches():
+    ft = H.field_table_from_oracle()
+    a, sa, _ = synth.make_state(ft, 6016, tier="B", seed=5)
+    b, sb, _ = synth.make_state(ft, 6016, tier="B", seed=5)
+    assert sa == sb and all(np.array_equal(a[k], b[k]) for k in a)
+    c, _, _ = synth.make_state(ft, 6016, tier="B", seed=6)
+    assert not np.array_equal(a["snl"], c["snl"])
+    assert set(np.unique(a["snl"])) == {0, 1, 2, 3, 4, 5} and set(np.unique(a["vtype"])) == {12, 14}
+    assert a["do_capsnow"].any() and (a["h2osno"][a["do_capsnow"] == 1] > 1000).all()
+    tA, _, _ = synth.make_state(ft, 470, tier="A", seed=1)
+    assert (tA["snl"] == 0).all() and (tA["frac_veg_nosno"] == 1).all()
+    # a snow layer's water content is consistent with h2osno
+    lay = a["snl"] > 0
+    tot = (a["h2osoi_ice"][:, :5] + a["h2osoi_liq"][:, :5]).sum(axis=1)
+    assert np.allclose(tot[lay], a["h2osno"][lay])
+
+
+def test_pft_and_snicar_packing():
+    pft, optics = synth.load_params()
+    psn, alb, z0mr, displar = st.pack_pft(pft)
+    S = O.OracleState(1)
+    S.load_params(pft, optics)
+    assert np.array_equal(psn, S.pft_psn) and np.array_equal(alb, S.pft_alb)
+    assert np.array_equal(z0mr, S.z0mr) and np.array_equal(displar, S.displar)
+    assert psn[12, st.PSN_FIELDS.index("c3psn")] == 1.0 and psn[14, st.PSN_FIELDS.index("c3psn")] == 0.0
+    assert sum(_lib.SNICAR_SIZES.values()) == 18 * 5 + 6 * 5 * 1471 + 6 * 50 + 400
+    for name in _lib.SNICAR_NAMES:
+        assert optics[name].size == _lib.SNICAR_SIZES[name], name
+
+
+def test_golden_fixture_shapes():
+    for module, nsteps in (("CanopyHydrology", 49), ("CanopyFluxes", 97), ("SurfaceAlbedo", 95)):
+        d = F.load(module)
+        assert len(d["steps"]) == nsteps
+    d = F.load("CanopyHydrology")
+    assert d["in/t_soisno"].shape == (49, 20) and d["in/zi"].shape == (49, 21)
+    assert np.isnan(d["in/qflx_snwcp_ice"]).any() and (d["in/qflx_irrig"] == 1e36).any()  # sentinels kept as data

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""GPU box, under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: a calibration copy of known size with the kernels' own
+access shape (8 bytes per lane), then a few timesteps.  python tests/tools/traffic_probe.py [cols] [tier]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import bench  # noqa: E402
+from elmkernels_amd import state as st  # noqa: E402
+
+cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+tier = sys.argv[2] if len(sys.argv) > 2 else "B"
+D, _ = bench.build_state(cols, 0, tier, 0x5EEDE1A0)
+print("copy GB/s (1 GiB buffers, 8 B/lane):", D.copy_bandwidth(1 << 30, 5))
+for _ in range(3):
+    D.restore_fields()
+    st.timestep7(D, 1800.0)
+D.sync()
+print("done")

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libelmk.so")
+# ELMK_LIBRARY selects another build of the same ABI (development: kernel variants under test)
+LIB_PATH = os.environ.get("ELMK_LIBRARY") or os.path.join(HERE, "libelmk.so")
 
 # every symbol include/elmk.h declares: (restype, argtypes)
 _P = C.c_void_p
@@ -48,6 +49,7 @@ SIGNATURES = {
     "elmk_error_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]),
     "elmk_clear_errors": (C.c_int, [_P]),
     "elmk_profile_timestep7": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "elmk_read_scratch": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64]),
     "elmk_copy_bandwidth": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
 }
 

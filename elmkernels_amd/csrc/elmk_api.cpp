@@ -610,6 +610,30 @@ int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_k
   return ELMK_OK;
 }
 
+int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64_t count)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (!host || offset < 0 || count < 0) return invalid(ctx, "elmk_read_scratch: bad arguments");
+  const void* src = nullptr;
+  size_t esz = 0;
+  int64_t limit = 0;
+  if (kind == ELMK_SCRATCH_CF_TRIPS) {
+    src = ctx->h.cf_niter;
+    esz = 4;
+    limit = ctx->ncols;
+  } else if (kind == ELMK_SCRATCH_WORK) {
+    src = ctx->h.wk;
+    esz = 8;
+    limit = (int64_t)WK_N * ctx->ld;
+  } else {
+    return invalid(ctx, "elmk_read_scratch: unknown kind");
+  }
+  if (offset + count > limit) return invalid(ctx, "elmk_read_scratch: range exceeds the scratch array");
+  HIPCHK(hipMemcpyAsync(host, (const char*)src + (size_t)offset * esz, (size_t)count * esz, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ELMK_OK;
+}
+
 int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_per_s)
 {
   if (int rc = enter(ctx)) return rc;

@@ -102,6 +102,7 @@ enum : int {
   WK_CF_JMAXC,
   WK_CF_TPUC,
   WK_CF_LMRC,
+  WK_DEBUG,        // development probes only (per-wave timeline of k_cf_iterate, CF_PROBE builds)
   WK_N
 };
 enum : int {
@@ -312,20 +313,132 @@ __device__ __forceinline__ double fv_profile(double zldis, double obu, double z0
   return VKC / (log(obu / z0) + 5.0 - 5.0 * z0 / obu + (5.0 * log(zeta) + zeta - 1.0));
 }
 
-// the five calls that open every stability iteration (bareground_fluxes_impl.hh:52-57, canopy_fluxes_impl.hh:235-240)
-__device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
-                                                  double obu, double z0m, double z0h, double z0q, double& ustar,
-                                                  double& temp1, double& temp2, double& temp12m, double& temp22m)
+// stab1(x) and stab2(x) of the same argument: stab2(x) is twice the second logarithm of stab1(x) (:17-33)
+__device__ __forceinline__ void stab12(double zeta, double& s1, double& s2)
 {
-  ustar = fv_wind(hgt_u, displa, um, obu, z0m);
-  temp1 = fv_profile<false>(hgt_t - displa, obu, z0h);                     // friction_velocity_temp :86
-  if (hgt_q == hgt_t && z0q == z0h) {                                      // friction_velocity_humidity :107
+  const double chik2 = sqrt(1.0 - 16.0 * zeta);
+  const double chik = sqrt(chik2);
+  const double lg2 = log((1.0 + chik2) * 0.5);
+  s1 = 2.0 * log((1.0 + chik) * 0.5) + lg2 - 2.0 * atan(chik) + ELM_PI * 0.5;
+  s2 = 2.0 * lg2;
+}
+
+// zetam^0.333 and zetat^-0.333 of the very unstable regime (:70, :91); evaluated once per kernel
+struct FvConst {
+  double pw_m, pw_t;
+};
+__device__ __forceinline__ FvConst fv_const()
+{
+  FvConst k;
+  k.pw_m = pow(1.574, 0.333);
+  k.pw_t = pow(0.465, -0.333);
+  return k;
+}
+
+// The five calls that open every stability iteration (bareground_fluxes_impl.hh:52-57, canopy_fluxes_impl.hh:235-240):
+// friction_velocity_wind :64, _temp :86, _humidity :107, _temp2m :134, _humidity2m :153.
+//
+// Each profile has four stability regimes with different transcendental calls, and the lanes of a wave sit in
+// different regimes, so a call-by-call transcription executes nearly every branch of every call.  Here the three
+// distinct profiles (wind, temperature, 2 m temperature; the humidity ones equal the temperature ones when their
+// heights and roughness lengths do, as the reference itself short-cuts) are evaluated together: one logarithm per
+// profile on a regime-selected argument, ONE unstable block (all three profiles are unstable together, zeta has
+// the sign of obu) in which stab1/stab2 of z0/obu are shared, one very-unstable block for the pow terms and one
+// very-stable block for log(zeta).  Every lane still evaluates exactly the reference's expression for its regime
+// on the same operands, so results are bit-identical to the call-by-call form (fv_wind / fv_profile above).
+// SAME_Z0: z0m, z0h and z0q are the same value (canopy); otherwise z0h == z0q is still checked at run time.
+template <bool SAME_Z0>
+__device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
+                                                  double obu, double z0m, double z0h, double z0q, const FvConst& K,
+                                                  double& ustar, double& temp1, double& temp2, double& temp12m,
+                                                  double& temp22m)
+{
+  const double zetam = 1.574, zetat = 0.465;
+  const double zl_u = hgt_u - displa, ze_u = zl_u / obu;  // wind
+  const double zl_t = hgt_t - displa, ze_t = zl_t / obu;  // temperature
+  const double zl_2 = 2.0 + z0h, ze_2 = zl_2 / obu;       // 2 m temperature
+  // regimes in the reference's test order: very unstable, unstable, stable (zeta <= 1), else very stable
+  const bool u1 = ze_u < -zetam, u2 = !u1 && ze_u < 0.0, u3 = !u1 && !u2 && ze_u <= 1.0;
+  const bool t1 = ze_t < -zetat, t2 = !t1 && ze_t < 0.0, t3 = !t1 && !t2 && ze_t <= 1.0;
+  const bool b1 = ze_2 < -zetat, b2 = !b1 && ze_2 < 0.0, b3 = !b1 && !b2 && ze_2 <= 1.0;
+
+  const double au = u1 ? (-zetam * obu / z0m) : ((u2 || u3) ? (zl_u / z0m) : (obu / z0m));
+  const double at = t1 ? (-zetat * obu / z0h) : ((t2 || t3) ? (zl_t / z0h) : (obu / z0h));
+  const double a2 = b1 ? (-zetat * obu / z0h) : ((b2 || b3) ? (zl_2 / z0h) : (obu / z0h));
+  const double Lu = log(au);
+  double Lt = Lu;
+  if (!(at == au)) Lt = log(at);
+  double L2 = Lt;
+  if (!(a2 == at)) L2 = log(a2);
+
+  double su = 0.0, st = 0.0, s2 = 0.0, sz1 = 0.0, sz2 = 0.0;
+  if (u1 || u2 || t1 || t2 || b1 || b2) {
+    if (SAME_Z0) {
+      stab12(z0m / obu, sz1, sz2);
+    } else {
+      sz1 = stab1(z0m / obu);
+      sz2 = stab2(z0h / obu);
+    }
+    su = stab1(u1 ? -zetam : ze_u);
+    const double xt = t1 ? -zetat : ze_t;
+    const double x2 = b1 ? -zetat : ze_2;
+    st = stab2(xt);
+    s2 = st;
+    if (!(x2 == xt)) s2 = stab2(x2);
+  }
+  double pu = 0.0, pt = 0.0, p2 = 0.0;
+  if (u1 || t1 || b1) {
+    if (u1) pu = pow((-ze_u), 0.333);
+    if (t1) pt = pow((-ze_t), -0.333);
+    p2 = pt;
+    if (b1 && !(ze_2 == ze_t && t1)) p2 = pow((-ze_2), -0.333);
+  }
+  const bool u4 = !u1 && !u2 && !u3, t4 = !t1 && !t2 && !t3, b4 = !b1 && !b2 && !b3;
+  double lu = 0.0, lt = 0.0, l2 = 0.0;
+  if (u4 || t4 || b4) {
+    if (u4) lu = log(ze_u);
+    lt = lu;
+    if (t4 && !(ze_t == ze_u && u4)) lt = log(ze_t);
+    if (b4) l2 = log(ze_2);
+  }
+
+  double du, dt, d2;
+  if (u1) {
+    du = Lu - su + sz1 + 1.14 * (pu - K.pw_m);
+  } else if (u2) {
+    du = Lu - su + sz1;
+  } else if (u3) {
+    du = Lu + 5.0 * ze_u - 5.0 * z0m / obu;
+  } else {
+    du = Lu + 5.0 - 5.0 * z0m / obu + (5.0 * lu + ze_u - 1.0);
+  }
+  if (t1) {
+    dt = Lt - st + sz2 + 0.8 * (K.pw_t - pt);
+  } else if (t2) {
+    dt = Lt - st + sz2;
+  } else if (t3) {
+    dt = Lt + 5.0 * ze_t - 5.0 * z0h / obu;
+  } else {
+    dt = Lt + 5.0 - 5.0 * z0h / obu + (5.0 * lt + ze_t - 1.0);
+  }
+  if (b1) {
+    d2 = L2 - s2 + sz2 + 0.8 * (K.pw_t - p2);
+  } else if (b2) {
+    d2 = L2 - s2 + sz2;
+  } else if (b3) {
+    d2 = L2 + 5.0 * ze_2 - 5.0 * z0h / obu;
+  } else {
+    d2 = L2 + 5.0 - 5.0 * (z0h / obu) + (5.0 * l2 + ze_2 - 1.0);  // the grouping only friction_velocity_temp2m has (:148)
+  }
+  ustar = VKC * um / du;
+  temp1 = VKC / dt;
+  temp12m = VKC / d2;
+  if (hgt_q == hgt_t && z0q == z0h) {  // friction_velocity_humidity :107
     temp2 = temp1;
   } else {
     temp2 = fv_profile<false>(hgt_q - displa, obu, z0q);
   }
-  temp12m = fv_profile<true>(2.0 + z0h, obu, z0h);                         // friction_velocity_temp2m :134
-  if (z0q == z0h) {                                                        // friction_velocity_humidity2m :153
+  if (z0q == z0h) {  // friction_velocity_humidity2m :153
     temp22m = temp12m;
   } else {
     temp22m = fv_profile<false>(2.0 + z0q, obu, z0q);

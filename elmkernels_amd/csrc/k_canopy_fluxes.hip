@@ -114,7 +114,10 @@ __device__ __forceinline__ double ci_func(double ci, CiCtx& k)
 }
 
 // photosynthesis_impl.hh:396-511
-__device__ __noinline__ double psn_brent(double x1, double x2, double f1, double f2, double tol, CiCtx& k)
+#ifndef CF_BRENT_ATTR
+#define CF_BRENT_ATTR __forceinline__  // not a call: see the note at psn_hybrid
+#endif
+__device__ CF_BRENT_ATTR double psn_brent(double x1, double x2, double f1, double f2, double tol, CiCtx& k)
 {
   const int ITMAX = 20;
   const double EPS = 1.0e-2;
@@ -179,6 +182,8 @@ __device__ __noinline__ double psn_brent(double x1, double x2, double f1, double
   return b;
 }
 
+// Brent's method is inlined: as a real call it sat inside divergent control flow of a kernel that spills SGPRs to
+// VGPR lanes, and a build with a few more live SGPRs corrupted the state of the lanes that were inactive at the call.
 // photosynthesis_impl.hh:517-620 (x0 is only an output in the reference; its final value is never read again,
 // what survives the solve is the CiCtx state of the LAST ci_func evaluation)
 __device__ __forceinline__ void psn_hybrid(double x0, CiCtx& k)
@@ -221,6 +226,39 @@ __device__ __forceinline__ void psn_hybrid(double x0, CiCtx& k)
       break;
     }
   }
+}
+
+// t_veg-dependent factors of one trip (photosynthesis_impl.hh:63-135); the carboxylation / electron-transport /
+// Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase
+__device__ __forceinline__ PsnTemp psn_temp(const PsnInv& I, const double* __restrict__ P, double t_veg, bool day)
+{
+  PsnTemp T;
+  T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
+  T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
+  if (I.c3flag) {
+    T.ft_lmr = psn_ft(t_veg, P[P_lmrha]);
+    T.fth_lmr = psn_fth(t_veg, P[P_lmrhd], P[P_lmrse], I.lmrc);
+  } else {
+    T.p2 = pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+    T.e_lmr_c4 = exp(1.3 * (t_veg - (TFRZ + 55.0)));
+  }
+  if (day) {
+    if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
+      T.ft_vcmax = psn_ft(t_veg, P[P_vcmaxha]);
+      T.fth_vcmax = psn_fth(t_veg, P[P_vcmaxhd], I.vcmaxse, I.vcmaxc);
+    } else {
+      T.e_vc4a = exp(0.2 * ((TFRZ + 15.0) - t_veg));
+      T.e_vc4b = exp(0.3 * (t_veg - (TFRZ + 40.0)));
+    }
+    T.ft_jmax = psn_ft(t_veg, P[P_jmaxha]);
+    T.fth_jmax = psn_fth(t_veg, P[P_jmaxhd], I.jmaxse, I.jmaxc);
+    T.ft_tpu = psn_ft(t_veg, P[P_tpuha]);
+    T.fth_tpu = psn_fth(t_veg, P[P_tpuhd], I.tpuse, I.tpuc);
+    T.kc = I.kc25 * psn_ft(t_veg, P[P_kcha]);
+    T.ko = I.ko25 * psn_ft(t_veg, P[P_koha]);
+    T.cp = I.cp25 * psn_ft(t_veg, P[P_cpha]);
+  }
+  return T;
 }
 
 // photosynthesis() for one phase (sunlit or shaded), nlevcan == 1 (:63-282)
@@ -456,6 +494,9 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 // column (trip counts range from 3 to 41).  Refill is batched (REFILL_MIN idle lanes, or nothing left to do).
 // =====================================================================================================
 constexpr int CF_REFILL_MIN = 8;
+#ifndef CF_PROBE
+#define CF_PROBE 0  // 1..3: development cost probes (tests/tools/cf_probe.sh), never set in the product build
+#endif
 
 struct CfLane {  // per-column inputs held while the column iterates
   double forc_pbot, forc_q, forc_th, forc_rho, forc_po2, forc_pco2, thm, thv, elai, esai, emv, emg, qg, t_grnd,
@@ -474,13 +515,35 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
   const double dl = S->dayl, mdl = S->max_dayl;
   const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
+  const FvConst FV = fv_const();
 
-  // the four work lists form one queue; their lengths are final (k_cf_init has completed)
+  // the four work lists form one queue; their lengths are final (k_cf_init has completed).  Night columns ride in
+  // the idle lanes of waves that are still busy with day columns: their trip is a subset of the day trip.
   const uint32_t n0 = ELMK_LIST_COUNT(S, LIST_CF_DAY_LONG);
   const uint32_t n1 = n0 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT_LONG);
   const uint32_t n2 = n1 + ELMK_LIST_COUNT(S, LIST_CF_DAY);
   const uint32_t n3 = n2 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT);
   bool exhausted = false;   // wave-uniform: the queue is empty
+#if CF_PROBE
+  const double pz = S->dewmx * 0.0;
+  (void)pz;
+#endif
+#if CF_PROBE >= 4  // per-wave timeline: start, queue-exhausted and end time (100 MHz ticks), trips, active lane-trips
+  const uint64_t pr_t0 = wall_clock64();
+  uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0;
+#endif
+#if CF_PROBE == 5  // shader-clock cycles per section of the loop (wave-uniform accumulators)
+  uint64_t pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t pr_last = clock64();
+#define PR_T(i)                      \
+  {                                  \
+    const uint64_t t_ = clock64();   \
+    pr_acc[i] += t_ - pr_last;       \
+    pr_last = t_;                    \
+  }
+#else
+#define PR_T(i)
+#endif
   int64_t c = -1;           // column owned by this lane (-1: idle)
 
   CfLane in;
@@ -524,6 +587,10 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         c = S->lists[(int64_t)(LIST_CF_DAY_LONG + li) * ld + off];
       }
       if (base + (uint32_t)__popcll(m) >= n3) exhausted = true;
+#if CF_PROBE >= 4
+      pr_refills++;
+      if (exhausted && !pr_texh) pr_texh = wall_clock64();
+#endif
     }
     // lanes that just received a column (P not set yet) gather its inputs and set up the iteration
     if (c >= 0 && P == nullptr) {
@@ -643,12 +710,29 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       if (exhausted) break;
       continue;
     }
+    PR_T(0)
+#if CF_PROBE >= 4
+    pr_trips++;
+    pr_lanes += (uint64_t)__popcll(__ballot(c >= 0));
+#endif
 
     // ---------------- one trip of the leaf-temperature iteration (:233-450) ----------------
     if (c >= 0) {
       double ustar;
-      friction_profiles(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, ustar, temp1, temp2,
-                        temp12m, temp22m);
+      friction_profiles<true>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, FV, ustar, temp1,
+                              temp2, temp12m, temp22m);
+      PR_T(1)
+#if CF_PROBE == 1  // cost probe: evaluate the part twice on bit-identical inputs the compiler cannot prove identical
+      {
+        double u2, a2, b2, c2, d2;
+        friction_profiles<true>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um + pz, obu + pz, in.z0mv, in.z0mv, in.z0mv, FV, u2, a2, b2, c2, d2);
+        ustar = (ustar + u2) * 0.5;
+        temp1 = (temp1 + a2) * 0.5;
+        temp2 = (temp2 + b2) * 0.5;
+        temp12m = (temp12m + c2) * 0.5;
+        temp22m = (temp22m + d2) * 0.5;
+      }
+#endif
       tlbef = t_veg;
       const double del2 = del;
       const double ram = 1.0 / (ustar * ustar / um);
@@ -672,41 +756,45 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double svpts = el;
       const double eah = in.forc_pbot * qaf / 0.622;
 
-      // temperature factors of this trip, shared by both phases; the carboxylation / electron-transport /
-      // Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase
-      PsnTemp T;
-      T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
-      T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
-      if (I.c3flag) {
-        T.ft_lmr = psn_ft(t_veg, P[P_lmrha]);
-        T.fth_lmr = psn_fth(t_veg, P[P_lmrhd], P[P_lmrse], I.lmrc);
-      } else {
-        T.p2 = pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
-        T.e_lmr_c4 = exp(1.3 * (t_veg - (TFRZ + 55.0)));
+      // temperature factors of this trip, shared by both phases
+#if CF_PROBE == 2
+      PsnTemp T = psn_temp(I, P, t_veg, in.day);
+      {
+        const PsnTemp T2 = psn_temp(I, P, t_veg + pz, in.day);
+        T.ft_lmr = (T.ft_lmr + T2.ft_lmr) * 0.5;
+        T.fth_lmr = (T.fth_lmr + T2.fth_lmr) * 0.5;
+        T.p2 = (T.p2 + T2.p2) * 0.5;
+        T.e_lmr_c4 = (T.e_lmr_c4 + T2.e_lmr_c4) * 0.5;
+        T.e_vc4a = (T.e_vc4a + T2.e_vc4a) * 0.5;
+        T.e_vc4b = (T.e_vc4b + T2.e_vc4b) * 0.5;
+        T.ft_vcmax = (T.ft_vcmax + T2.ft_vcmax) * 0.5;
+        T.fth_vcmax = (T.fth_vcmax + T2.fth_vcmax) * 0.5;
+        T.ft_jmax = (T.ft_jmax + T2.ft_jmax) * 0.5;
+        T.fth_jmax = (T.fth_jmax + T2.fth_jmax) * 0.5;
+        T.ft_tpu = (T.ft_tpu + T2.ft_tpu) * 0.5;
+        T.fth_tpu = (T.fth_tpu + T2.fth_tpu) * 0.5;
+        T.kc = (T.kc + T2.kc) * 0.5;
+        T.ko = (T.ko + T2.ko) * 0.5;
+        T.cp = (T.cp + T2.cp) * 0.5;
       }
-      if (in.day) {
-        if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
-          T.ft_vcmax = psn_ft(t_veg, P[P_vcmaxha]);
-          T.fth_vcmax = psn_fth(t_veg, P[P_vcmaxhd], I.vcmaxse, I.vcmaxc);
-        } else {
-          T.e_vc4a = exp(0.2 * ((TFRZ + 15.0) - t_veg));
-          T.e_vc4b = exp(0.3 * (t_veg - (TFRZ + 40.0)));
-        }
-        T.ft_jmax = psn_ft(t_veg, P[P_jmaxha]);
-        T.fth_jmax = psn_fth(t_veg, P[P_jmaxhd], I.jmaxse, I.jmaxc);
-        T.ft_tpu = psn_ft(t_veg, P[P_tpuha]);
-        T.fth_tpu = psn_fth(t_veg, P[P_tpuhd], I.tpuse, I.tpuc);
-        T.kc = I.kc25 * psn_ft(t_veg, P[P_kcha]);
-        T.ko = I.ko25 * psn_ft(t_veg, P[P_koha]);
-        T.cp = I.cp25 * psn_ft(t_veg, P[P_cpha]);
-      }
+#else
+      const PsnTemp T = psn_temp(I, P, t_veg, in.day);
+#endif
 
+      PR_T(2)
       if (soy) btran = dmin(1.0, btran * 1.25);
       const double rssun = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
                                      in.vcmaxcintsun, in.parsun, in.lai_sun_z, err);
+      PR_T(3)
       if (soy) btran = dmin(1.0, btran * 1.25);
       const double rssha = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
-                                     in.vcmaxcintsha, in.parsha, in.lai_sha_z, err);
+                                     in.vcmaxcintsha, in.parsha, in.lai_sha_z, err)
+#if CF_PROBE == 3
+                           * 0.5 + 0.5 * psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb + pz, btran,
+                                                   in.vcmaxcintsha, in.parsha, in.lai_sha_z, err)
+#endif
+          ;
+      PR_T(4)
 
       const double wta = 1.0 / rah0;
       const double wtl = (in.elai + in.esai) / rb;
@@ -825,6 +913,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       }
       if (itlef > 40) stop = true;  // itmax: while (itlef <= itmax && !stop)
 
+      PR_T(5)
       // ---------------- converged: compute_flux (:456-540), store, release the lane ----------------
       if (stop) {
         S->btran[c] = btran;
@@ -872,8 +961,28 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         c = -1;
         P = nullptr;
       }
+      PR_T(6)
+#if CF_PROBE >= 4
+      pr_cols += (uint64_t)__popcll(__ballot(stop));
+#endif
     }
   }
+#if CF_PROBE >= 4
+  if (lane == 0) {
+    double* o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+#if CF_PROBE == 5
+    for (int i = 0; i < 8; i++) o[8 + i] = (double)pr_acc[i];
+#endif
+    o[0] = (double)pr_t0;
+    o[1] = (double)pr_texh;
+    o[2] = (double)wall_clock64();
+    o[3] = (double)pr_trips;
+    o[4] = (double)pr_lanes;
+    o[5] = (double)pr_refills;
+    o[6] = (double)pr_cols;
+    o[7] = 1.0;
+  }
+#endif
 }
 
 __global__ void k_cf_reset(const DevState* __restrict__ S)

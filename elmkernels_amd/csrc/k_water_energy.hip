@@ -678,11 +678,12 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
   monin_obukhov_length(ur, thv, dthv, zldis, z0mg, um, obu);
 
   // ---- stability_iteration: 3 fixed iterations
+  const FvConst FV = fv_const();
   double z0hg = S->z0hg[c], z0qg = S->z0qg[c];
   double ustar = 0.0, temp1 = 0.0, temp2 = 0.0, temp12m = 0.0, temp22m = 0.0;
 #pragma unroll 1
   for (int i = 0; i < 3; i++) {
-    friction_profiles(hgt_u, hgt_t, hgt_q, displa, um, obu, z0mg, z0hg, z0qg, ustar, temp1, temp2, temp12m, temp22m);
+    friction_profiles<false>(hgt_u, hgt_t, hgt_q, displa, um, obu, z0mg, z0hg, z0qg, FV, ustar, temp1, temp2, temp12m, temp22m);
     const double tstar = temp1 * dth;
     const double qstar = temp2 * dqh;
     const double thvstar = tstar * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * qstar;

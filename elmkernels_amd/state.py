@@ -199,6 +199,17 @@ class ELMState:
         self._chk(self.lib.elmk_profile_timestep7(self.ctx, float(dt), int(nsteps), ms, C.byref(tot)), "profile_timestep7")
         return list(ms), tot.value
 
+    def canopy_trip_counts(self):
+        """Trips of the leaf-temperature iteration per column in the last canopy_fluxes call (0: not vegetated)."""
+        out = np.zeros(self.ncols, dtype=np.int32)
+        self._chk(self.lib.elmk_read_scratch(self.ctx, 0, out.ctypes.data_as(C.c_void_p), 0, self.ncols), "read_scratch")
+        return out
+
+    def read_work(self, offset, count):
+        out = np.zeros(int(count), dtype=np.float64)
+        self._chk(self.lib.elmk_read_scratch(self.ctx, 1, out.ctypes.data_as(C.c_void_p), int(offset), int(count)), "read_scratch")
+        return out
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=20):
         g = C.c_double()
         self._chk(self.lib.elmk_copy_bandwidth(self.ctx, int(nbytes), int(iters), C.byref(g)), "copy_bandwidth")

@@ -192,6 +192,13 @@ int elmk_clear_errors(elmk_ctx *ctx);
  * time of one whole timestep (first event to last).  If a snapshot exists (elmk_snapshot_fields) it is
  * restored before every step, outside the event brackets, so each profiled step does the same work. */
 int elmk_profile_timestep7(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_kernel, float *ms_total);
+/* Read back context-owned scratch (diagnostics; not part of the state contract).
+ *   ELMK_SCRATCH_CF_TRIPS: int32 per column - trips of the leaf-temperature iteration
+ *                          (canopy_fluxes_impl.hh:233-450) in the last elmk_canopy_fluxes call, 0 = not vegetated
+ *   ELMK_SCRATCH_WORK:     doubles of the work arrays, raw (development probes)
+ * Synchronises the stream. */
+enum { ELMK_SCRATCH_CF_TRIPS = 0, ELMK_SCRATCH_WORK = 1 };
+int elmk_read_scratch(elmk_ctx *ctx, int kind, void *host, int64_t offset, int64_t count);
 /* device-to-device copy bandwidth probe (read+write bytes / s) on this context's device, used as the
  * empirical HBM line next to the 8 TB/s datasheet peak */
 int elmk_copy_bandwidth(elmk_ctx *ctx, int64_t bytes, int iters, double *gbytes_per_s);

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""GPU box, development: trip-count histogram of canopy_fluxes and, with a CF_PROBE=4 build selected through
+ELMK_LIBRARY, the per-wave timeline of k_cf_iterate.  python tests/tools/cf_timeline.py [cols]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import bench  # noqa: E402
+from elmkernels_amd import state as st  # noqa: E402
+
+cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+D, _ = bench.build_state(cols, 0, "B", 0x5EEDE1A0)
+for _ in range(3):
+    D.restore_fields()
+    st.timestep7(D, 1800.0)
+D.sync()
+trips = D.canopy_trip_counts()
+veg = trips > 0
+day = (D.download("nrad") > 0) & ((D.download("parsun_z").reshape(cols, -1)[:, 0] > 0) | (D.download("parsha_z").reshape(cols, -1)[:, 0] > 0))
+print(f"columns {cols}: vegetated {veg.sum()} day {int((veg & day).sum())} night {int((veg & ~day).sum())}")
+for name, m in (("day", veg & day), ("night", veg & ~day)):
+    t = trips[m]
+    h = np.bincount(t, minlength=42)
+    print(name, "mean trips %.2f" % t.mean(), "hist", {i: int(v) for i, v in enumerate(h) if v})
+ld = D.level_stride
+WK_DEBUG = 7
+nw = 2048
+w = D.read_work(WK_DEBUG * ld, nw * 16).reshape(nw, 16)
+w = w[w[:, 7] == 1.0]
+if len(w):
+    t0 = w[:, 0].min()
+    start, exh, end = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0, (w[:, 2] - t0) / 100.0  # us
+    exh = np.where(w[:, 1] > 0, exh, np.nan)
+    print(f"waves that ran: {len(w)}; start max {start.max():.0f} us; queue exhausted at {np.nanmin(exh):.0f}..{np.nanmax(exh):.0f} us")
+    print("end time percentiles (us):", {p: round(float(np.percentile(end, p))) for p in (0, 10, 50, 90, 99, 100)})
+    busy = w[:, 3] > 0
+    print(f"waves with work: {busy.sum()}, trips/wave mean {w[busy, 3].mean():.1f} max {w[busy, 3].max():.0f}; "
+          f"lane utilisation over trips {w[busy, 4].sum() / (64 * w[busy, 3].sum()):.3f}; refills/wave {w[busy, 5].mean():.1f}; "
+          f"us per trip {((end - start)[busy].sum() / w[busy, 3].sum()):.1f}")
+    # utilisation before / after the queue ran dry is not separable per trip here; report the tail length instead
+    print(f"tail: last wave ends {end.max() - np.nanmin(exh):.0f} us after the queue ran dry (kernel {end.max():.0f} us)")
+    sec = w[busy, 8:16].sum(axis=0)
+    if sec.sum() > 0:
+        names = ["refill+setup", "friction", "resistances+psn_temp", "psn sun", "psn shade", "energy balance", "epilogue", "-"]
+        print("shader-clock share per section:", {n: round(float(v / sec.sum()), 3) for n, v in zip(names, sec) if n != "-"},
+              "cycles/trip", round(float(sec.sum() / w[busy, 3].sum())))
+else:
+    print("no timeline (product build)")
+D.close()

@@ -164,9 +164,16 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
   const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
   const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
-  const size_t cnt_bytes = align_up((size_t)2 * NLISTS * CPAD * 4, 256);
+  const size_t cnt_bytes = align_up((size_t)(2 * NLISTS + CF_NCLS) * CPAD * 4, 256);
   const size_t hint_bytes = align_up((size_t)ctx->ld * 4, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes;
+  // canopy_fluxes queue records (k_canopy_fluxes.hip), by queue position
+  const int64_t cf_nblk = (ncols + 255) / 256 > 0 ? (ncols + 255) / 256 : 1;
+  const size_t rec_bytes = align_up((size_t)CF_REC_N * (size_t)(ctx->ld + 8) * 8, 256);
+  const size_t fin_bytes = align_up((size_t)CF_FIN_N * (size_t)(ctx->ld + 8) * 8, 256);
+  const size_t irec_bytes = align_up((size_t)CF_IREC_N * (size_t)ctx->ld * 4, 256);
+  const size_t pos_bytes = align_up((size_t)ctx->ld * 4, 256);
+  const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -193,6 +200,19 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.lists = (int32_t*)(ctx->scratch + wk_bytes);
   h.counters = (uint32_t*)(ctx->scratch + wk_bytes + list_bytes);
   h.cf_niter = (int32_t*)(ctx->scratch + wk_bytes + list_bytes + cnt_bytes);
+  {
+    char* q = ctx->scratch + wk_bytes + list_bytes + cnt_bytes + hint_bytes;
+    h.cf_rec = (double*)q;
+    q += rec_bytes;
+    h.cf_fin = (double*)q;
+    q += fin_bytes;
+    h.cf_irec = (int32_t*)q;
+    q += irec_bytes;
+    h.cf_pos = (int32_t*)q;
+    q += pos_bytes;
+    h.cf_blk = (uint32_t*)q;
+    h.cf_nblk = cf_nblk;
+  }
   {
     int f = 0;
 #define ELMK_FIELD(name, T, nlev) h.name = (ctype_of<ELMK_##T>::type*)ctx->fptr[f++];
@@ -631,6 +651,8 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
   if (offset + count > limit) return invalid(ctx, "elmk_read_scratch: range exceeds the scratch array");
   HIPCHK(hipMemcpyAsync(host, (const char*)src + (size_t)offset * esz, (size_t)count * esz, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (kind == ELMK_SCRATCH_CF_TRIPS)  // the high half of each word is the scheduler's hint
+    for (int64_t i = 0; i < count; i++) ((int32_t*)host)[i] &= 0xFFFF;
   return ELMK_OK;
 }
 

@@ -95,33 +95,27 @@ enum : int {
 
 // work arrays and work lists of the compacted (queue-driven) kernels
 enum : int {
-  WK_CF_UM = 0,    // canopy_fluxes: initial wind speed / Obukhov length from monin_obukhov_length
-  WK_CF_OBU,
-  WK_CF_LWGRND,    // ground-emitted longwave term (three pow(T,4))
-  WK_CF_VCMAXC,    // fth25() scaling factors of photosynthesis
-  WK_CF_JMAXC,
-  WK_CF_TPUC,
-  WK_CF_LMRC,
-  WK_DEBUG,        // development probes only (per-wave timeline of k_cf_iterate, CF_PROBE builds)
+  WK_CF_LWGRND = 0,  // canopy_fluxes: ground-emitted longwave term (three pow(T,4)), by column
+  WK_DEBUG,          // development probes only (per-wave timeline of k_cf_iterate, CF_PROBE builds)
   WK_N
 };
 enum : int {
-  // canopy_fluxes: vegetated columns, by PAR (day: a leaf class absorbs PAR) and by the trip count of the previous
-  // call (long first: longest-processing-time-first keeps the tail of the persistent kernel short).  The four lists
-  // are drained in this order as one queue (head counter of LIST_CF_DAY_LONG).
-  LIST_CF_DAY_LONG = 0,
-  LIST_CF_NIGHT_LONG,
-  LIST_CF_DAY,
-  LIST_CF_NIGHT,
-  LIST_BG,           // bare-ground columns
-  LIST_ALB_0,        // sunlit snow-free columns (soil albedo + canopy two-stream only)
-  LIST_ALB_1,        // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
+  LIST_CF_QUEUE = 0,  // canopy_fluxes work queue: only its length and head counters are used (k_canopy_fluxes.hip)
+  LIST_BG,            // bare-ground columns
+  LIST_ALB_0,         // sunlit snow-free columns (soil albedo + canopy two-stream only)
+  LIST_ALB_1,         // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
   LIST_ALB_2,
   LIST_ALB_3,
   LIST_ALB_4,
   LIST_ALB_5,
   NLISTS
 };
+
+// canopy_fluxes queue records (k_canopy_fluxes.hip): per queue position, SoA [k][position] with stride ld
+constexpr int CF_NCLS = 12;    // scheduling classes: 6 bins of the previous call's trip count x (day, night)
+constexpr int CF_REC_N = 62;   // doubles a column carries into the iteration kernel
+constexpr int CF_IREC_N = 3;   // int32: vtype, nrad, frac_veg_nosno
+constexpr int CF_FIN_N = 24;   // doubles the iteration kernel hands to the finishing kernel
 
 // Queue counters live one per 128-byte line (same-line atomics serialise in one L2 channel):
 // length of list k at counters[k * CPAD], queue head of list k at counters[(NLISTS + k) * CPAD].
@@ -181,6 +175,12 @@ struct DevState {
   int32_t* lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
   uint32_t* counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
   int32_t* cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
+  double* cf_rec;      // CF_REC_N x ld: inputs of the queued columns, by queue position
+  double* cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position
+  int32_t* cf_irec;    // CF_IREC_N x ld
+  int32_t* cf_pos;     // queue position of each column (-1: not vegetated)
+  uint32_t* cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
+  int64_t cf_nblk;     // workgroups of 256 columns
 #define ELMK_FIELD(name, T, nlev) ctype_of<ELMK_##T>::type* name;
 #include "elmk_fields.def"
 #undef ELMK_FIELD
@@ -347,7 +347,8 @@ __device__ __forceinline__ FvConst fv_const()
 // very-stable block for log(zeta).  Every lane still evaluates exactly the reference's expression for its regime
 // on the same operands, so results are bit-identical to the call-by-call form (fv_wind / fv_profile above).
 // SAME_Z0: z0m, z0h and z0q are the same value (canopy); otherwise z0h == z0q is still checked at run time.
-template <bool SAME_Z0>
+// WITH_2M = false leaves temp12m / temp22m untouched (the caller evaluates the 2 m profile later with fv_profile).
+template <bool SAME_Z0, bool WITH_2M = true>
 __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
                                                   double obu, double z0m, double z0h, double z0q, const FvConst& K,
                                                   double& ustar, double& temp1, double& temp2, double& temp12m,
@@ -360,7 +361,7 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   // regimes in the reference's test order: very unstable, unstable, stable (zeta <= 1), else very stable
   const bool u1 = ze_u < -zetam, u2 = !u1 && ze_u < 0.0, u3 = !u1 && !u2 && ze_u <= 1.0;
   const bool t1 = ze_t < -zetat, t2 = !t1 && ze_t < 0.0, t3 = !t1 && !t2 && ze_t <= 1.0;
-  const bool b1 = ze_2 < -zetat, b2 = !b1 && ze_2 < 0.0, b3 = !b1 && !b2 && ze_2 <= 1.0;
+  const bool b1 = WITH_2M && ze_2 < -zetat, b2 = WITH_2M && !b1 && ze_2 < 0.0, b3 = !WITH_2M || (!b1 && !b2 && ze_2 <= 1.0);
 
   const double au = u1 ? (-zetam * obu / z0m) : ((u2 || u3) ? (zl_u / z0m) : (obu / z0m));
   const double at = t1 ? (-zetat * obu / z0h) : ((t2 || t3) ? (zl_t / z0h) : (obu / z0h));
@@ -369,7 +370,7 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   double Lt = Lu;
   if (!(at == au)) Lt = log(at);
   double L2 = Lt;
-  if (!(a2 == at)) L2 = log(a2);
+  if (WITH_2M && !(a2 == at)) L2 = log(a2);
 
   double su = 0.0, st = 0.0, s2 = 0.0, sz1 = 0.0, sz2 = 0.0;
   if (u1 || u2 || t1 || t2 || b1 || b2) {
@@ -384,7 +385,7 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
     const double x2 = b1 ? -zetat : ze_2;
     st = stab2(xt);
     s2 = st;
-    if (!(x2 == xt)) s2 = stab2(x2);
+    if (WITH_2M && !(x2 == xt)) s2 = stab2(x2);
   }
   double pu = 0.0, pt = 0.0, p2 = 0.0;
   if (u1 || t1 || b1) {
@@ -432,16 +433,18 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   }
   ustar = VKC * um / du;
   temp1 = VKC / dt;
-  temp12m = VKC / d2;
+  if (WITH_2M) temp12m = VKC / d2;
   if (hgt_q == hgt_t && z0q == z0h) {  // friction_velocity_humidity :107
     temp2 = temp1;
   } else {
     temp2 = fv_profile<false>(hgt_q - displa, obu, z0q);
   }
-  if (z0q == z0h) {  // friction_velocity_humidity2m :153
-    temp22m = temp12m;
-  } else {
-    temp22m = fv_profile<false>(2.0 + z0q, obu, z0q);
+  if (WITH_2M) {
+    if (z0q == z0h) {  // friction_velocity_humidity2m :153
+      temp22m = temp12m;
+    } else {
+      temp22m = fv_profile<false>(2.0 + z0q, obu, z0q);
+    }
   }
 }
 

@@ -24,8 +24,6 @@ namespace elmk {
 
 #define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
 
-constexpr int CF_LONG_TRIPS = 14;  // previous-call trip count from which a column is scheduled first
-
 // photosynthesis_impl.hh:623-635
 __device__ __forceinline__ double psn_ft(double tl, double ha)
 {
@@ -363,22 +361,165 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
 
 
 // =====================================================================================================
-// Launch 1 of 2: k_cf_init - one thread per column, coalesced.
-//   * bare / urban columns: the whole wrapper (initialize_flux bare branch + compute_flux's cgrnd reset);
-//   * vegetated columns: initialize_flux (:129-182): root moisture stress over the 15 soil levels, canopy
-//     roughness blend, Monin-Obukhov initial guess; plus the column-invariant exp() factors of photosynthesis;
-//     then the column is queued for the iteration kernel (day list if either leaf class has PAR, else night list).
+// Launch structure.  The leaf-temperature iteration has data-dependent trip counts (3..41) and is fp64-compute
+// bound; everything around it is streaming work.  So the wrapper is four launches:
+//
+//   k_cf_count   per column: scheduling class (bin of the previous call's trip count x day/night); every workgroup
+//                takes a slice of each class with one atomic.  Classes are laid end to end in ONE work queue that
+//                is sorted longest-expected-first (LPT keeps the tail of the persistent kernel short)
+//   k_cf_init    coalesced, one thread per column: the bare-ground branch; for vegetated columns initialize_flux
+//                (:129-182) and every loop-invariant quantity of the iteration, written as a RECORD at the column's
+//                queue position (SoA by position: a refill of consecutive positions is a coalesced read)
+//   k_cf_iterate persistent waves; each lane carries one column through stability_iteration (:187-452) and, when
+//                it converges, stores the converged state at the queue position and takes the next position
+//   k_cf_finish  coalesced, one thread per column: compute_flux (:456-540), the 2 m profile, state writes
 // =====================================================================================================
+#ifndef CF_PROBE
+#define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
+#endif
+constexpr int CF_REFILL_MIN = 8;
+
+// doubles of a queue record (k_cf_init -> k_cf_iterate)
+#define CF_REC_FIELDS(X)                                                                                               \
+  X(forc_pbot) X(forc_q) X(forc_th) X(forc_rho) X(thm) X(thv) X(elai) X(esai) X(qg) X(t_grnd) X(z0mg) X(z0mv)          \
+  X(hgt_u) X(hgt_t) X(hgt_q) X(displa) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha) X(rdl_num) X(soilbeta)        \
+  X(sabv) X(h2ocan) X(air) X(bir) X(cir) X(lw_grnd) X(sqrt_dleaf) X(w_lai) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun)   \
+  X(parsha) X(lai_sun_z) X(lai_sha_z)                                                                                  \
+  X(vcmax25top) X(jmax25top) X(tpu25top) X(kp25top) X(lmr25top) X(vcmaxse) X(jmaxse) X(vcmaxc) X(jmaxc) X(tpuc)        \
+  X(lmrc) X(cf) X(cp25) X(qe) X(theta_cj) X(bbbopt) X(mbbopt)                                                          \
+  X(t_veg) X(btran) X(um) X(obu) X(el) X(qsatl) X(qsatldT)
+// doubles of a finish record (k_cf_iterate -> k_cf_finish)
+#define CF_FIN_FIELDS(X)                                                                                               \
+  X(t_veg) X(btran) X(qflx_tran_veg) X(qflx_evap_veg) X(eflx_sh_veg) X(wtg) X(wtl0) X(wta0) X(wtal) X(wtgq) X(wtalq)   \
+  X(wtlq0) X(wtaq0) X(delq) X(qsatl) X(temp1) X(temp2) X(dth) X(dqh) X(tlbef) X(dt_veg) X(obu_trip) X(trips) X(err)
+
+struct CfRec {
+#define X(n) double n;
+  CF_REC_FIELDS(X)
+#undef X
+};
+enum : int {
+#define X(n) REC_##n,
+  CF_REC_FIELDS(X)
+#undef X
+  REC_COUNT
+};
+struct CfFin {
+#define X(n) double n;
+  CF_FIN_FIELDS(X)
+#undef X
+};
+enum : int {
+#define X(n) FIN_##n,
+  CF_FIN_FIELDS(X)
+#undef X
+  FIN_COUNT
+};
+// Records are stored in blocks of 8 consecutive queue positions: block b holds field k of positions 8b..8b+7 at
+// [b][k][0..7] (64 contiguous bytes), so all fields of neighbouring positions share a few DRAM pages, a refill batch
+// of consecutive positions reads 64-byte runs, and the writers' partial runs merge in L2.
+#define CF_REC_BASE(pos) (((pos) >> 3) * (int64_t)(CF_REC_N * 8) + ((pos)&7))
+#define CF_FIN_BASE(pos) (((pos) >> 3) * (int64_t)(CF_FIN_N * 8) + ((pos)&7))
+static_assert(REC_COUNT == CF_REC_N && FIN_COUNT == CF_FIN_N, "record sizes in elmk_dev.h out of date");
+enum : int { IREC_vtype = 0, IREC_nrad, IREC_fvn };
+
+// class totals of the current call: counters behind the list counters, one per 128-byte line; zero on entry
+// (elmk_create clears them, k_cf_finish clears them again for the next call)
+#define CF_CLASS_COUNT(S, k) ((S)->counters[(2 * NLISTS + (k)) * CPAD])
+
+// scheduling class of a column, -1 if it is not vegetated (lake land units are handled by the callers)
+__device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const Land& L, int64_t c, bool inside)
+{
+  if (!inside || L.urbpoi) return -1;
+  if (S->frac_veg_nosno[c] == 0) return -1;
+  const bool day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
+  const int prev = S->cf_niter[c] >> 16;  // scheduling hint (see k_cf_finish); 0: never iterated -> middle bin
+  int bin = 3;
+  if (prev >= 22) {
+    bin = 0;
+  } else if (prev >= 16) {
+    bin = 1;
+  } else if (prev >= 12) {
+    bin = 2;
+  } else if (prev >= 9) {
+    bin = 3;
+  } else if (prev >= 6) {
+    bin = 4;
+  } else if (prev >= 1) {
+    bin = 5;
+  }
+  // all day columns before the night ones: a day column can jump from a handful of trips to the 40-trip limit from
+  // one call to the next (a few per 100000 do), a night column was never seen to; so a mispredicted long column
+  // still starts in the first half of the queue, and the end of the queue is reliably short work
+  return (day ? 0 : CF_NCLS / 2) + bin;
+}
+
+__global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S)
+{
+  __shared__ uint32_t s_cnt[CF_NCLS];
+  if (threadIdx.x < CF_NCLS) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const Land L = S->land;
+  const int cls = L.lakpoi ? -1 : cf_class(S, L, c, c < S->ncols);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < CF_NCLS; k++) {
+    const unsigned long long m = __ballot(cls == k);
+    if (lane == 0 && m) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+  }
+  __syncthreads();
+  // this workgroup's slice of class k: [returned value, + count) relative to the start of the class
+  if (threadIdx.x < CF_NCLS) {
+    const uint32_t n = s_cnt[threadIdx.x];
+    S->cf_blk[(int64_t)threadIdx.x * S->cf_nblk + blockIdx.x] = n ? atomicAdd(&CF_CLASS_COUNT(S, threadIdx.x), n) : 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 {
+  __shared__ uint32_t s_w[4][CF_NCLS];
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   const Land L = S->land;
-  if (L.lakpoi) return;
+  if (L.lakpoi) {  // uniform: the wrapper does nothing on lake land units
+    if (blockIdx.x == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+    return;
+  }
   const bool inside = c < S->ncols;
-  const int fvn = inside ? S->frac_veg_nosno[c] : 0;
-  bool veg = inside && !L.urbpoi && fvn != 0;
-  bool day = false;
+  const int cls = cf_class(S, L, c, inside);
+  const bool veg = cls >= 0;
+
+  // queue position: slice of (class, workgroup) from k_cf_count, then (wave, lane) order inside the workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t rank = 0u;
+#pragma unroll
+  for (int k = 0; k < CF_NCLS; k++) {
+    const unsigned long long m = __ballot(cls == k);
+    if (lane == 0) s_w[wave][k] = (uint32_t)__popcll(m);
+    if (cls == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  int64_t pos = -1;
+  {
+    // start of each class in the queue = total of the classes before it (final: k_cf_count has completed)
+    uint32_t start = 0u, mine = 0u;
+#pragma unroll
+    for (int k = 0; k < CF_NCLS; k++) {
+      if (k == cls) mine = start;
+      start += CF_CLASS_COUNT(S, k);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = start;
+      ELMK_LIST_HEAD(S, LIST_CF_QUEUE) = 0u;
+    }
+    if (veg) {
+      uint32_t off = mine + S->cf_blk[(int64_t)cls * S->cf_nblk + blockIdx.x];
+      for (int w = 0; w < wave; w++) off += s_w[w][cls];
+      pos = (int64_t)off + rank;
+    }
+  }
+  if (inside) S->cf_pos[c] = (int32_t)pos;
 
   if (inside && !veg) {
     if (!L.urbpoi) {
@@ -391,143 +532,216 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     S->cgrnds[c] = 0.0;
     S->cgrndl[c] = 0.0;
   }
-  if (veg) {
-    const int snl = S->snl[c];
-    const double* __restrict__ P = S->pft_psn[S->vtype[c]];
-    const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
-    double btran = 0.0;  // btran0
-    double rootr[NLEVGRND];
-    double t_soi0 = 0.0;
+  if (!veg) return;
+
+  CfRec r;
+  const int snl = S->snl[c];
+  const int vtype = S->vtype[c];
+  const double* __restrict__ P = S->pft_psn[vtype];
+  const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
+  double btran = 0.0;  // btran0
+  double rootr[NLEVGRND];
+  double t_soi0 = 0.0;
 #pragma unroll
-    for (int i = 0; i < NLEVGRND; i++) {
-      const double watsat = LV(watsat, i);
-      const double dzi = LV(dz, NLEVSNO + i);
-      // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
-      const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
-      const double eff_por = watsat - vol_ice;
-      LV(eff_porosity, i) = eff_por;
-      // calc_volumetric_h2oliq (:77-86)
-      const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
-      // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
-      const double tsoi = LV(t_soisno, NLEVSNO + i);
-      if (i == 0) t_soi0 = tsoi;
-      if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
-        rootr[i] = 0.0;
-      } else {
-        const double s_node = dmax(liqvol / eff_por, 0.01);
-        double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
-        smp_node = dmax(smpsc, smp_node);
-        const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
-        rootr[i] = LV(rootfr, i) * rresis;
-        btran += dmax(rootr[i], 0.0);
-      }
+  for (int i = 0; i < NLEVGRND; i++) {
+    const double watsat = LV(watsat, i);
+    const double dzi = LV(dz, NLEVSNO + i);
+    // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
+    const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
+    const double eff_por = watsat - vol_ice;
+    LV(eff_porosity, i) = eff_por;
+    // calc_volumetric_h2oliq (:77-86)
+    const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
+    // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
+    const double tsoi = LV(t_soisno, NLEVSNO + i);
+    if (i == 0) t_soi0 = tsoi;
+    if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
+      rootr[i] = 0.0;
+    } else {
+      const double s_node = dmax(liqvol / eff_por, 0.01);
+      double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
+      smp_node = dmax(smpsc, smp_node);
+      const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
+      rootr[i] = LV(rootfr, i) * rresis;
+      btran += dmax(rootr[i], 0.0);
     }
-#pragma unroll
-    for (int i = 0; i < NLEVGRND; i++) {
-      double r = rootr[i];
-      if (btran > 0.0) {
-        r /= btran;
-      } else {
-        r = 0.0;
-      }
-      LV(rootr, i) = r;
-    }
-    S->btran[c] = btran;
-    const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
-
-    // canopy roughness blend (:141-147)
-    const double elai = S->elai[c], esai = S->esai[c], z0mg = S->z0mg[c];
-    const double tlsai_crit = 2.0;
-    const double lt = dmin(elai + esai, tlsai_crit);
-    const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
-    double displa = S->displa[c];
-    displa *= egvf;
-    double z0mv = S->z0mv[c];
-    z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(z0mg));
-    S->displa[c] = displa;
-    S->z0mv[c] = z0mv;
-    S->z0hv[c] = z0mv;
-    S->z0qv[c] = z0mv;
-
-    // initial flux profile and Monin-Obukhov length (:158-181)
-    const double thm = S->thm[c], forc_q = S->forc_qbot[c], qg = S->qg[c], t_grnd = S->t_grnd[c];
-    const double taf = (t_grnd + thm) / 2.0;
-    const double qaf = (forc_q + qg) / 2.0;
-    const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
-    const double ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
-    const double dth = thm - taf;
-    const double dqh = forc_q - qaf;
-    const double dthv = dth * (1.0 + 0.61 * forc_q) + 0.61 * S->forc_thbot[c] * dqh;
-    const double zldis = S->forc_hgt_u_patch[c] - displa;
-    if (!(zldis >= 0.0)) S->err_flags[c] |= ELMK_ERR_CANFLX_FORC_HGT;
-    double um, obu;
-    monin_obukhov_length(ur, S->thv[c], dthv, zldis, z0mv, um, obu);
-    S->wk[(int64_t)WK_CF_UM * ld + c] = um;
-    S->wk[(int64_t)WK_CF_OBU * ld + c] = obu;
-
-    // ground-emitted longwave (:366-367), loop-invariant
-    const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
-    S->wk[(int64_t)WK_CF_LWGRND * ld + c] = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
-                                             frac_h2osfc * pow(S->t_h2osfc[c], 4.0));
-
-    // high-temperature scaling factors of photosynthesis (photosynthesis_impl.hh:91, :109-114)
-    const double t10 = S->t10[c];
-    const double vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    const double jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    S->wk[(int64_t)WK_CF_VCMAXC * ld + c] = psn_fth25(P[P_vcmaxhd], vcmaxse);
-    S->wk[(int64_t)WK_CF_JMAXC * ld + c] = psn_fth25(P[P_jmaxhd], jmaxse);
-    S->wk[(int64_t)WK_CF_TPUC * ld + c] = psn_fth25(P[P_tpuhd], vcmaxse);
-    S->wk[(int64_t)WK_CF_LMRC * ld + c] = psn_fth25(P[P_lmrhd], P[P_lmrse]);
-
-    day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
   }
-  // scheduling class: columns that needed many trips last time go to the front of the queue
-  int cls = -1;
-  if (veg) cls = ((S->cf_niter[c] >= CF_LONG_TRIPS) ? 0 : 2) + (day ? 0 : 1);
-  block_classify_append<4>(S->lists, ld, S->counters, LIST_CF_DAY_LONG, cls, (int32_t)c);
+#pragma unroll
+  for (int i = 0; i < NLEVGRND; i++) {
+    double q = rootr[i];
+    if (btran > 0.0) {
+      q /= btran;
+    } else {
+      q = 0.0;
+    }
+    LV(rootr, i) = q;
+  }
+  S->btran[c] = btran;
+  r.btran = btran;
+  const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
+
+  // canopy roughness blend (canopy_fluxes_impl.hh:141-147)
+  r.elai = S->elai[c];
+  r.esai = S->esai[c];
+  r.z0mg = S->z0mg[c];
+  const double tlsai_crit = 2.0;
+  const double lt = dmin(r.elai + r.esai, tlsai_crit);
+  const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
+  double displa = S->displa[c];
+  displa *= egvf;
+  double z0mv = S->z0mv[c];
+  z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(r.z0mg));
+  S->displa[c] = displa;
+  S->z0mv[c] = z0mv;
+  S->z0hv[c] = z0mv;
+  S->z0qv[c] = z0mv;
+  r.displa = displa;
+  r.z0mv = z0mv;
+
+  // forcing, derived forcing (atm_physics_impl.hh:246-272) and the wrapper-level inputs of the iteration
+  r.forc_pbot = S->forc_pbot[c];
+  r.forc_q = S->forc_qbot[c];
+  r.forc_th = S->forc_thbot[c];
+  r.forc_rho = derive_forc_rho(r.forc_pbot, r.forc_q, S->forc_tbot[c]);
+  r.thm = S->thm[c];
+  r.thv = S->thv[c];
+  r.qg = S->qg[c];
+  r.t_grnd = S->t_grnd[c];
+  r.hgt_u = S->forc_hgt_u_patch[c];
+  r.hgt_t = S->forc_hgt_t_patch[c];
+  r.hgt_q = S->forc_hgt_q_patch[c];
+  const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
+  r.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+  r.htop = S->htop[c];
+  r.fwet = S->fwet[c];
+  r.fdry = S->fdry[c];
+  r.laisun = S->laisun[c];
+  r.laisha = S->laisha[c];
+  r.soilbeta = S->soilbeta[c];
+  r.sabv = S->sabv[c];
+  r.h2ocan = S->h2ocan[c];
+  const double emv = S->emv[c], emg = S->emg[c];
+  r.air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * S->forc_lwrad[c];  // :360-362
+  r.bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
+  r.cir = emv * emg * STEBOL;
+  r.vcmaxcintsun = S->vcmaxcintsun[c];
+  r.vcmaxcintsha = S->vcmaxcintsha[c];
+  const int nrad = S->nrad[c];
+  r.parsun = r.parsha = r.lai_sun_z = r.lai_sha_z = 0.0;
+  if (nrad > 0) {
+    r.parsun = S->parsun_z[c];
+    r.parsha = S->parsha_z[c];
+    r.lai_sun_z = S->laisun_z[c];
+    r.lai_sha_z = S->laisha_z[c];
+  }
+  // loop-invariant sub-expressions of the iteration body (:272, :301-303, :270)
+  r.w_lai = exp(-(r.elai + r.esai));
+  {
+    const double snow_depth_c = 0.05;
+    const double fsno_dl = S->snow_depth[c] / snow_depth_c;
+    const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
+    r.rdl_num = (1.0 - exp(-elai_dl));
+  }
+  r.sqrt_dleaf = sqrt(P[P_dleaf]);
+
+  // initial flux profile and Monin-Obukhov length (:158-181)
+  {
+    const double taf = (r.t_grnd + r.thm) / 2.0;
+    const double qaf = (r.forc_q + r.qg) / 2.0;
+    const double dth = r.thm - taf;
+    const double dqh = r.forc_q - qaf;
+    const double dthv = dth * (1.0 + 0.61 * r.forc_q) + 0.61 * r.forc_th * dqh;
+    const double zldis = r.hgt_u - displa;
+    if (!(zldis >= 0.0)) S->err_flags[c] |= ELMK_ERR_CANFLX_FORC_HGT;
+    monin_obukhov_length(r.ur, r.thv, dthv, zldis, z0mv, r.um, r.obu);
+  }
+
+  // ground-emitted longwave (:366-367), loop-invariant
+  const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
+  r.lw_grnd = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
+               frac_h2osfc * pow(S->t_h2osfc[c], 4.0));
+  S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
+
+  // iteration-invariant part of photosynthesis() (photosynthesis_impl.hh:22-61, :91, :109-114, :135, :152-154)
+  {
+    const double dl = S->dayl, mdl = S->max_dayl;
+    const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
+    const double t10 = S->t10[c];
+    const bool c3flag = (round(P[P_c3psn]) == 1);
+    const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
+    const double act25 = P[P_act25] * 1000.0 / 60.0;
+    double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
+    vcmax25top *= P[P_fnitr];
+    r.vcmax25top = vcmax25top;
+    r.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
+    r.tpu25top = 0.167 * vcmax25top;
+    r.kp25top = 20000.0 * vcmax25top;
+    r.lmr25top = c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
+    r.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    r.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    r.vcmaxc = psn_fth25(P[P_vcmaxhd], r.vcmaxse);
+    r.jmaxc = psn_fth25(P[P_jmaxhd], r.jmaxse);
+    r.tpuc = psn_fth25(P[P_tpuhd], r.vcmaxse);
+    r.lmrc = psn_fth25(P[P_lmrhd], P[P_lmrse]);
+    r.cf = r.forc_pbot / (RGAS * 1.0e-3 * r.thm) * 1.e06;
+    const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
+    r.cp25 = 0.5 * derive_forc_po2(r.forc_pbot) / sco;
+    r.qe = P[P_qe];
+    r.theta_cj = P[P_theta_cj];
+    r.bbbopt = P[P_bbbopt];
+    r.mbbopt = P[P_mbbopt];
+  }
+
+  // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
+  r.t_veg = S->t_veg[c];
+  {
+    double deldT;
+    qsat(r.t_veg, r.forc_pbot, r.el, deldT, r.qsatl, r.qsatldT);
+  }
+
+  double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
+#define X(n) rec[REC_##n * 8] = r.n;
+  CF_REC_FIELDS(X)
+#undef X
+  int32_t* __restrict__ irec = S->cf_irec + pos;
+  irec[(int64_t)IREC_vtype * ld] = vtype;
+  irec[(int64_t)IREC_nrad * ld] = nrad;
+  irec[(int64_t)IREC_fvn * ld] = S->frac_veg_nosno[c];
 }
 
 // =====================================================================================================
-// Launch 2 of 2: k_cf_iterate - persistent waves drain the day queue, then the night queue.
-// Every lane carries one column through the leaf-temperature iteration; a lane whose column has converged
-// runs compute_flux, stores, and takes the next column from the queue, so the wave never waits for its slowest
-// column (trip counts range from 3 to 41).  Refill is batched (REFILL_MIN idle lanes, or nothing left to do).
+// k_cf_iterate - persistent waves drain the queue.  Every lane carries one column through the leaf-temperature
+// iteration; a lane whose column has converged stores the converged state at its queue position and takes the next
+// position, so a wave never waits for its slowest column (trip counts range from 3 to 41).  Refill is batched
+// (CF_REFILL_MIN idle lanes, or nothing left to do): the lanes of a batch take consecutive positions, so the record
+// loads are coalesced.  Night columns ride in the idle lanes of waves busy with day columns: their trip is a subset.
 // =====================================================================================================
-constexpr int CF_REFILL_MIN = 8;
-#ifndef CF_PROBE
-#define CF_PROBE 0  // 1..3: development cost probes (tests/tools/cf_probe.sh), never set in the product build
-#endif
-
-struct CfLane {  // per-column inputs held while the column iterates
-  double forc_pbot, forc_q, forc_th, forc_rho, forc_po2, forc_pco2, thm, thv, elai, esai, emv, emg, qg, t_grnd,
-      forc_lwrad, z0mg, z0mv, hgt_u, hgt_t, hgt_q, displa, zldis, ur, htop, fwet, fdry, laisun, laisha, snow_depth,
-      soilbeta, sabv, h2ocan, air, bir, cir, lw_grnd, dleaf, vcmaxcintsun, vcmaxcintsha, parsun, parsha, lai_sun_z,
-      lai_sha_z, t_top, t_soi0, t_h2osfc;
-  int nrad, fvn;
-  bool day;
-};
-
 __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
 {
   const int64_t ld = S->ld;
   const Land L = S->land;
   const int lane = threadIdx.x & 63;
   const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
-  const double dl = S->dayl, mdl = S->max_dayl;
-  const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
   const FvConst FV = fv_const();
+  const uint32_t nq = ELMK_LIST_COUNT(S, LIST_CF_QUEUE);  // final: written by k_cf_init
+  bool exhausted = false;  // wave-uniform: the queue is empty
+  int64_t pos = -1;        // queue position owned by this lane (-1: idle)
+  bool fresh = false;      // the lane has just received a position and must load its record
 
-  // the four work lists form one queue; their lengths are final (k_cf_init has completed).  Night columns ride in
-  // the idle lanes of waves that are still busy with day columns: their trip is a subset of the day trip.
-  const uint32_t n0 = ELMK_LIST_COUNT(S, LIST_CF_DAY_LONG);
-  const uint32_t n1 = n0 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT_LONG);
-  const uint32_t n2 = n1 + ELMK_LIST_COUNT(S, LIST_CF_DAY);
-  const uint32_t n3 = n2 + ELMK_LIST_COUNT(S, LIST_CF_NIGHT);
-  bool exhausted = false;   // wave-uniform: the queue is empty
-#if CF_PROBE
-  const double pz = S->dewmx * 0.0;
-  (void)pz;
-#endif
+  CfRec in;
+  PsnInv I;
+  const double* __restrict__ P = nullptr;
+  int nrad = 0, fvn = 0;
+  bool day = false;
+  double forc_po2 = 0.0, forc_pco2 = 0.0, zldis = 0.0;
+  uint32_t err = 0;
+  // loop-carried state of stability_iteration
+  double t_veg = 0.0, btran = 0.0, um = 0.0, obu = 0.0, taf = 0.0, qaf = 0.0, el = 0.0, qsatl = 0.0, qsatldT = 0.0;
+  double dth = 0.0, dqh = 0.0, delq = 0.0, del = 0.0, efeb = 0.0, obuold = 0.0;
+  double qflx_tran_veg = 0.0, qflx_evap_veg = 0.0, eflx_sh_veg = 0.0;
+  double wtg = 0.0, wtl0 = 0.0, wta0 = 0.0, wtal = 0.0, wtgq = 0.0, wtalq = 0.0, wtlq0 = 0.0, wtaq0 = 0.0;
+  double temp1 = 0.0, temp2 = 0.0, tlbef = 0.0, dt_veg = 0.0;
+  int itlef = 0, nmozsgn = 0;
 #if CF_PROBE >= 4  // per-wave timeline: start, queue-exhausted and end time (100 MHz ticks), trips, active lane-trips
   const uint64_t pr_t0 = wall_clock64();
   uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0;
@@ -535,167 +749,85 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 #if CF_PROBE == 5  // shader-clock cycles per section of the loop (wave-uniform accumulators)
   uint64_t pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t pr_last = clock64();
-#define PR_T(i)                      \
-  {                                  \
-    const uint64_t t_ = clock64();   \
-    pr_acc[i] += t_ - pr_last;       \
-    pr_last = t_;                    \
+#define PR_T(i)                    \
+  {                                \
+    const uint64_t t_ = clock64(); \
+    pr_acc[i] += t_ - pr_last;     \
+    pr_last = t_;                  \
   }
 #else
 #define PR_T(i)
 #endif
-  int64_t c = -1;           // column owned by this lane (-1: idle)
-
-  CfLane in;
-  PsnInv I;
-  const double* __restrict__ P = nullptr;
-  uint32_t err = 0;
-  // loop-carried state of stability_iteration
-  double t_veg = 0.0, btran = 0.0, um = 0.0, obu = 0.0, taf = 0.0, qaf = 0.0, el = 0.0, qsatl = 0.0, qsatldT = 0.0;
-  double dth = 0.0, dqh = 0.0, delq = 0.0, del = 0.0, efeb = 0.0, obuold = 0.0;
-  double qflx_tran_veg = 0.0, qflx_evap_veg = 0.0, eflx_sh_veg = 0.0;
-  double wtg = 0.0, wtl0 = 0.0, wta0 = 0.0, wtal = 0.0, wtgq = 0.0, wtalq = 0.0, wtlq0 = 0.0, wtaq0 = 0.0;
-  double temp1 = 0.0, temp2 = 0.0, temp12m = 0.0, temp22m = 0.0, tlbef = 0.0, dt_veg = 0.0;
-  int itlef = 0, nmozsgn = 0;
 
   for (;;) {
     // ---------------- refill ----------------
     // Idle lanes are refilled in batches (>= CF_REFILL_MIN of them, which includes the all-idle wave) with one
     // wave-aggregated atomic on the queue head.
-    const int nidle = __popcll(__ballot(c < 0));
+    const int nidle = __popcll(__ballot(pos < 0));
     if (!exhausted && nidle >= CF_REFILL_MIN) {
-      const bool take = (c < 0);
+      const bool take = (pos < 0);
       const unsigned long long m = __ballot(take);
       const int leader = __ffsll((long long)m) - 1;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_DAY_LONG), (uint32_t)__popcll(m));
+      if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE), (uint32_t)__popcll(m));
       base = __shfl(base, leader, 64);
       const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (take && mine < n3) {
-        int li = 3;
-        uint32_t off = mine - n2;
-        if (mine < n0) {
-          li = 0;
-          off = mine;
-        } else if (mine < n1) {
-          li = 1;
-          off = mine - n0;
-        } else if (mine < n2) {
-          li = 2;
-          off = mine - n1;
-        }
-        c = S->lists[(int64_t)(LIST_CF_DAY_LONG + li) * ld + off];
+      if (take && mine < nq) {
+        pos = (int64_t)mine;
+        fresh = true;
       }
-      if (base + (uint32_t)__popcll(m) >= n3) exhausted = true;
+      if (base + (uint32_t)__popcll(m) >= nq) exhausted = true;
 #if CF_PROBE >= 4
       pr_refills++;
       if (exhausted && !pr_texh) pr_texh = wall_clock64();
 #endif
     }
-    // lanes that just received a column (P not set yet) gather its inputs and set up the iteration
-    if (c >= 0 && P == nullptr) {
-      P = S->pft_psn[S->vtype[c]];
-      in.fvn = S->frac_veg_nosno[c];
-      in.nrad = S->nrad[c];
-      in.forc_pbot = S->forc_pbot[c];
-      in.forc_q = S->forc_qbot[c];
-      in.forc_th = S->forc_thbot[c];
-      const double forc_t = S->forc_tbot[c];
-      in.forc_po2 = derive_forc_po2(in.forc_pbot);
-      in.forc_pco2 = derive_forc_pco2(in.forc_pbot);
-      in.forc_rho = derive_forc_rho(in.forc_pbot, in.forc_q, forc_t);
-      in.thm = S->thm[c];
-      in.thv = S->thv[c];
-      in.elai = S->elai[c];
-      in.esai = S->esai[c];
-      in.emv = S->emv[c];
-      in.emg = S->emg[c];
-      in.qg = S->qg[c];
-      in.t_grnd = S->t_grnd[c];
-      in.forc_lwrad = S->forc_lwrad[c];
-      in.z0mg = S->z0mg[c];
-      in.z0mv = S->z0mv[c];
-      in.hgt_u = S->forc_hgt_u_patch[c];
-      in.hgt_t = S->forc_hgt_t_patch[c];
-      in.hgt_q = S->forc_hgt_q_patch[c];
-      in.displa = S->displa[c];
-      in.zldis = in.hgt_u - in.displa;
-      const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
-      in.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
-      in.htop = S->htop[c];
-      in.fwet = S->fwet[c];
-      in.fdry = S->fdry[c];
-      in.laisun = S->laisun[c];
-      in.laisha = S->laisha[c];
-      in.snow_depth = S->snow_depth[c];
-      in.soilbeta = S->soilbeta[c];
-      in.sabv = S->sabv[c];
-      in.h2ocan = S->h2ocan[c];
-      in.air = in.emv * (1.0 + (1.0 - in.emv) * (1.0 - in.emg)) * in.forc_lwrad;
-      in.bir = -(2.0 - in.emv * (1.0 - in.emg)) * in.emv * STEBOL;
-      in.cir = in.emv * in.emg * STEBOL;
-      in.lw_grnd = S->wk[(int64_t)WK_CF_LWGRND * ld + c];
-      in.dleaf = P[P_dleaf];
-      in.vcmaxcintsun = S->vcmaxcintsun[c];
-      in.vcmaxcintsha = S->vcmaxcintsha[c];
-      in.parsun = in.parsha = in.lai_sun_z = in.lai_sha_z = 0.0;
-      if (in.nrad > 0) {
-        in.parsun = S->parsun_z[c];
-        in.parsha = S->parsha_z[c];
-        in.lai_sun_z = S->laisun_z[c];
-        in.lai_sha_z = S->laisha_z[c];
-      }
-      in.day = (in.nrad > 0) && (in.parsun > 0.0 || in.parsha > 0.0);
-      const int snl = S->snl[c];
-      in.t_soi0 = LV(t_soisno, NLEVSNO);
-      in.t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : in.t_soi0;
-      in.t_h2osfc = S->t_h2osfc[c];
-      // photosynthesis invariants (photosynthesis_impl.hh:22-61, :109-114, :135, :152-154)
-      {
-        const double t10 = S->t10[c];
-        const double c3psn = P[P_c3psn];
-        I.c3flag = false;
-        if (round(c3psn) == 1) {
-          I.c3flag = true;
-        } else if (round(c3psn) == 0) {
-          I.c3flag = false;
-        }
-        const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
-        const double act25 = P[P_act25] * 1000.0 / 60.0;
-        double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
-        vcmax25top *= P[P_fnitr];
-        I.vcmax25top = vcmax25top;
-        I.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
-        I.tpu25top = 0.167 * vcmax25top;
-        I.kp25top = 20000.0 * vcmax25top;
-        I.lmr25top = I.c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
-        I.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-        I.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-        I.tpuse = I.vcmaxse;
-        I.vcmaxc = S->wk[(int64_t)WK_CF_VCMAXC * ld + c];
-        I.jmaxc = S->wk[(int64_t)WK_CF_JMAXC * ld + c];
-        I.tpuc = S->wk[(int64_t)WK_CF_TPUC * ld + c];
-        I.lmrc = S->wk[(int64_t)WK_CF_LMRC * ld + c];
-        I.cf = in.forc_pbot / (RGAS * 1.0e-3 * in.thm) * 1.e06;
-        const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
-        I.kc25 = (404.9 / 1.e06) * in.forc_pbot;
-        I.ko25 = (278.4 / 1.e03) * in.forc_pbot;
-        I.cp25 = 0.5 * in.forc_po2 / sco;
-        I.qe = P[P_qe];
-        I.theta_cj = P[P_theta_cj];
-        I.bbbopt = P[P_bbbopt];
-        I.mbbopt = P[P_mbbopt];
-      }
+    if (fresh) {
+      fresh = false;
+      const double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
+#define X(n) in.n = rec[REC_##n * 8];
+      CF_REC_FIELDS(X)
+#undef X
+      const int32_t* __restrict__ irec = S->cf_irec + pos;
+      P = S->pft_psn[irec[(int64_t)IREC_vtype * ld]];
+      nrad = irec[(int64_t)IREC_nrad * ld];
+      fvn = irec[(int64_t)IREC_fvn * ld];
+      day = (nrad > 0) && (in.parsun > 0.0 || in.parsha > 0.0);
+      forc_po2 = derive_forc_po2(in.forc_pbot);
+      forc_pco2 = derive_forc_pco2(in.forc_pbot);
+      zldis = in.hgt_u - in.displa;
+      I.c3flag = (round(P[P_c3psn]) == 1);
+      I.vcmax25top = in.vcmax25top;
+      I.jmax25top = in.jmax25top;
+      I.tpu25top = in.tpu25top;
+      I.kp25top = in.kp25top;
+      I.lmr25top = in.lmr25top;
+      I.vcmaxse = in.vcmaxse;
+      I.jmaxse = in.jmaxse;
+      I.tpuse = in.vcmaxse;
+      I.vcmaxc = in.vcmaxc;
+      I.jmaxc = in.jmaxc;
+      I.tpuc = in.tpuc;
+      I.lmrc = in.lmrc;
+      I.cf = in.cf;
+      I.kc25 = (404.9 / 1.e06) * in.forc_pbot;
+      I.ko25 = (278.4 / 1.e03) * in.forc_pbot;
+      I.cp25 = in.cp25;
+      I.qe = in.qe;
+      I.theta_cj = in.theta_cj;
+      I.bbbopt = in.bbbopt;
+      I.mbbopt = in.mbbopt;
       // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
-      btran = S->btran[c];
-      t_veg = S->t_veg[c];
-      double deldT;
-      qsat(t_veg, in.forc_pbot, el, deldT, qsatl, qsatldT);
+      btran = in.btran;
+      t_veg = in.t_veg;
+      el = in.el;
+      qsatl = in.qsatl;
+      qsatldT = in.qsatldT;
       taf = (in.t_grnd + in.thm) / 2.0;
       qaf = (in.forc_q + in.qg) / 2.0;
       delq = in.qg - qaf;
-      um = S->wk[(int64_t)WK_CF_UM * ld + c];
-      obu = S->wk[(int64_t)WK_CF_OBU * ld + c];
+      um = in.um;
+      obu = in.obu;
       del = 0.0;
       efeb = 0.0;
       obuold = 0.0;
@@ -706,42 +838,33 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       qflx_evap_veg = 0.0;
       eflx_sh_veg = 0.0;
     }
-    if (__ballot(c >= 0) == 0ull) {
+    if (__ballot(pos >= 0) == 0ull) {
       if (exhausted) break;
       continue;
     }
     PR_T(0)
 #if CF_PROBE >= 4
     pr_trips++;
-    pr_lanes += (uint64_t)__popcll(__ballot(c >= 0));
+    pr_lanes += (uint64_t)__popcll(__ballot(pos >= 0));
 #endif
 
     // ---------------- one trip of the leaf-temperature iteration (:233-450) ----------------
-    if (c >= 0) {
-      double ustar;
-      friction_profiles<true>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, FV, ustar, temp1,
-                              temp2, temp12m, temp22m);
+    if (pos >= 0) {
+      double ustar, unused12m = 0.0, unused22m = 0.0;
+      const double obu_trip = obu;
+      // the 2 m profiles (:239-240) are only read by compute_flux: k_cf_finish evaluates them from obu_trip
+      friction_profiles<true, false>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, FV, ustar,
+                                     temp1, temp2, unused12m, unused22m);
       PR_T(1)
-#if CF_PROBE == 1  // cost probe: evaluate the part twice on bit-identical inputs the compiler cannot prove identical
-      {
-        double u2, a2, b2, c2, d2;
-        friction_profiles<true>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um + pz, obu + pz, in.z0mv, in.z0mv, in.z0mv, FV, u2, a2, b2, c2, d2);
-        ustar = (ustar + u2) * 0.5;
-        temp1 = (temp1 + a2) * 0.5;
-        temp2 = (temp2 + b2) * 0.5;
-        temp12m = (temp12m + c2) * 0.5;
-        temp22m = (temp22m + d2) * 0.5;
-      }
-#endif
       tlbef = t_veg;
       const double del2 = del;
       const double ram = 1.0 / (ustar * ustar / um);
       const double rah0 = 1.0 / (temp1 * ustar);
       const double raw0 = 1.0 / (temp2 * ustar);
       const double uaf = um * sqrt(1.0 / (ram * um));
-      const double cf = 0.01 / (sqrt(uaf) * sqrt(in.dleaf));
+      const double cf = 0.01 / (sqrt(uaf) * in.sqrt_dleaf);
       const double rb = 1.0 / (cf * uaf);
-      const double w = exp(-(in.elai + in.esai));
+      const double w = in.w_lai;
       const double csoilb = (VKC / (0.13 * pow((in.z0mg * uaf / 1.5e-5), 0.45)));
       const double ri = (GRAV * in.htop * (taf - in.t_grnd)) / (taf * pow(uaf, 2.0));
       double csoilcn;
@@ -757,43 +880,16 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double eah = in.forc_pbot * qaf / 0.622;
 
       // temperature factors of this trip, shared by both phases
-#if CF_PROBE == 2
-      PsnTemp T = psn_temp(I, P, t_veg, in.day);
-      {
-        const PsnTemp T2 = psn_temp(I, P, t_veg + pz, in.day);
-        T.ft_lmr = (T.ft_lmr + T2.ft_lmr) * 0.5;
-        T.fth_lmr = (T.fth_lmr + T2.fth_lmr) * 0.5;
-        T.p2 = (T.p2 + T2.p2) * 0.5;
-        T.e_lmr_c4 = (T.e_lmr_c4 + T2.e_lmr_c4) * 0.5;
-        T.e_vc4a = (T.e_vc4a + T2.e_vc4a) * 0.5;
-        T.e_vc4b = (T.e_vc4b + T2.e_vc4b) * 0.5;
-        T.ft_vcmax = (T.ft_vcmax + T2.ft_vcmax) * 0.5;
-        T.fth_vcmax = (T.fth_vcmax + T2.fth_vcmax) * 0.5;
-        T.ft_jmax = (T.ft_jmax + T2.ft_jmax) * 0.5;
-        T.fth_jmax = (T.fth_jmax + T2.fth_jmax) * 0.5;
-        T.ft_tpu = (T.ft_tpu + T2.ft_tpu) * 0.5;
-        T.fth_tpu = (T.fth_tpu + T2.fth_tpu) * 0.5;
-        T.kc = (T.kc + T2.kc) * 0.5;
-        T.ko = (T.ko + T2.ko) * 0.5;
-        T.cp = (T.cp + T2.cp) * 0.5;
-      }
-#else
-      const PsnTemp T = psn_temp(I, P, t_veg, in.day);
-#endif
+      const PsnTemp T = psn_temp(I, P, t_veg, day);
 
       PR_T(2)
       if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssun = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
-                                     in.vcmaxcintsun, in.parsun, in.lai_sun_z, err);
+      const double rssun = psn_phase(I, T, nrad, in.forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, in.vcmaxcintsun,
+                                     in.parsun, in.lai_sun_z, err);
       PR_T(3)
       if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssha = psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb, btran,
-                                     in.vcmaxcintsha, in.parsha, in.lai_sha_z, err)
-#if CF_PROBE == 3
-                           * 0.5 + 0.5 * psn_phase(I, T, in.nrad, in.forc_pbot, svpts, eah, in.forc_po2, in.forc_pco2, rb + pz, btran,
-                                                   in.vcmaxcintsha, in.parsha, in.lai_sha_z, err)
-#endif
-          ;
+      const double rssha = psn_phase(I, T, nrad, in.forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, in.vcmaxcintsha,
+                                     in.parsha, in.lai_sha_z, err);
       PR_T(4)
 
       const double wta = 1.0 / rah0;
@@ -828,16 +924,13 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         qflx_tran_veg = 0.0;
       }
 
-      const double wtaq = in.fvn / raw0;
-      const double wtlq = in.fvn * (in.elai + in.esai) / rb * rpp;
-      const double snow_depth_c = 0.05;
-      const double fsno_dl = in.snow_depth / snow_depth_c;
-      const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
-      const double rdl = (1.0 - exp(-elai_dl)) / (0.004 * uaf);
+      const double wtaq = fvn / raw0;
+      const double wtlq = fvn * (in.elai + in.esai) / rb * rpp;
+      const double rdl = in.rdl_num / (0.004 * uaf);
       if (delq < 0.0) {
-        wtgq = in.fvn / (raw1 + rdl);
+        wtgq = fvn / (raw1 + rdl);
       } else {
-        wtgq = in.soilbeta * in.fvn / (raw1 + rdl);
+        wtgq = in.soilbeta * fvn / (raw1 + rdl);
       }
       const double wtsqi = 1.0 / (wtaq + wtlq + wtgq);
       const double wtgq0 = wtgq * wtsqi;
@@ -889,7 +982,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double tstar = temp1 * dth;
       const double qstar = temp2 * dqh;
       const double thvstar = tstar * (1.0 + 0.61 * in.forc_q) + 0.61 * in.forc_th * qstar;
-      double zeta = in.zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * in.thv);
+      double zeta = zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * in.thv);
       if (zeta >= 0.0) {
         zeta = dmin(2.0, dmax(zeta, 0.01));
         um = dmax(in.ur, 0.1);
@@ -898,9 +991,9 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / in.thv), 0.333);
         um = sqrt(in.ur * in.ur + wc * wc);
       }
-      obu = in.zldis / zeta;
+      obu = zldis / zeta;
       if (obuold * obu < 0.0) nmozsgn += 1;
-      if (nmozsgn >= 4) obu = in.zldis / (-0.01);
+      if (nmozsgn >= 4) obu = zldis / (-0.01);
       obuold = obu;
 
       itlef += 1;
@@ -914,52 +1007,34 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       if (itlef > 40) stop = true;  // itmax: while (itlef <= itmax && !stop)
 
       PR_T(5)
-      // ---------------- converged: compute_flux (:456-540), store, release the lane ----------------
+      // ---------------- converged: hand the state to k_cf_finish, release the lane ----------------
       if (stop) {
-        S->btran[c] = btran;
-        S->t_veg[c] = t_veg;
-        S->qflx_tran_veg[c] = qflx_tran_veg;
-        S->qflx_evap_veg[c] = qflx_evap_veg;
-        S->eflx_sh_veg[c] = eflx_sh_veg;
-        const double thm = in.thm, t_grnd = in.t_grnd, forc_rho = in.forc_rho, forc_q = in.forc_q;
-        const double delt = wtal * t_grnd - wtl0 * t_veg - wta0 * thm;
-        S->eflx_sh_grnd[c] = CPAIR * forc_rho * wtg * delt;
-        const double delt_snow = wtal * in.t_top - wtl0 * t_veg - wta0 * thm;
-        S->eflx_sh_snow[c] = CPAIR * forc_rho * wtg * delt_snow;
-        const double delt_soil = wtal * in.t_soi0 - wtl0 * t_veg - wta0 * thm;
-        S->eflx_sh_soil[c] = CPAIR * forc_rho * wtg * delt_soil;
-        const double delt_h2osfc = wtal * in.t_h2osfc - wtl0 * t_veg - wta0 * thm;
-        S->eflx_sh_h2osfc[c] = CPAIR * forc_rho * wtg * delt_h2osfc;
-        S->qflx_evap_soi[c] = forc_rho * wtgq * delq;
-        const double delq_snow = wtalq * S->qg_snow[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-        S->qflx_ev_snow[c] = forc_rho * wtgq * delq_snow;
-        const double delq_soil = wtalq * S->qg_soil[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-        S->qflx_ev_soil[c] = forc_rho * wtgq * delq_soil;
-        const double delq_h2osfc = wtalq * S->qg_h2osfc[c] - wtlq0 * qsatl - wtaq0 * forc_q;
-        S->qflx_ev_h2osfc[c] = forc_rho * wtgq * delq_h2osfc;
-        const double t_ref2m = thm + temp1 * dth * (1.0 / temp12m - 1.0 / temp1);
-        const double q_ref2m = forc_q + temp2 * dqh * (1.0 / temp22m - 1.0 / temp2);
-        double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
-        qsat(t_ref2m, in.forc_pbot, e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT);
-        S->t_ref2m[c] = t_ref2m;
-        S->q_ref2m[c] = q_ref2m;
-        S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m) * 100.0);
-        const double emv = in.emv, emg = in.emg;
-        S->dlrad[c] = (1.0 - emv) * emg * in.forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
-        S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * in.forc_lwrad +
-                       emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
-                       emg * (1.0 - emv) * STEBOL * in.lw_grnd);
-        double cgrnds = 0.0, cgrndl = 0.0;
-        cgrnds += CPAIR * forc_rho * wtg * wtal;
-        cgrndl += forc_rho * wtgq * wtalq * S->dqgdT[c];
-        S->cgrnds[c] = cgrnds;
-        S->cgrndl[c] = cgrndl;
-        S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
-        S->h2ocan[c] = dmax(0.0, in.h2ocan + (qflx_tran_veg - qflx_evap_veg) * dtime);
-        if (err) S->err_flags[c] |= err;
-        S->cf_niter[c] = itlef;
-        c = -1;
-        P = nullptr;
+        double* __restrict__ fin = S->cf_fin + CF_FIN_BASE(pos);
+        fin[FIN_t_veg * 8] = t_veg;
+        fin[FIN_btran * 8] = btran;
+        fin[FIN_qflx_tran_veg * 8] = qflx_tran_veg;
+        fin[FIN_qflx_evap_veg * 8] = qflx_evap_veg;
+        fin[FIN_eflx_sh_veg * 8] = eflx_sh_veg;
+        fin[FIN_wtg * 8] = wtg;
+        fin[FIN_wtl0 * 8] = wtl0;
+        fin[FIN_wta0 * 8] = wta0;
+        fin[FIN_wtal * 8] = wtal;
+        fin[FIN_wtgq * 8] = wtgq;
+        fin[FIN_wtalq * 8] = wtalq;
+        fin[FIN_wtlq0 * 8] = wtlq0;
+        fin[FIN_wtaq0 * 8] = wtaq0;
+        fin[FIN_delq * 8] = delq;
+        fin[FIN_qsatl * 8] = qsatl;
+        fin[FIN_temp1 * 8] = temp1;
+        fin[FIN_temp2 * 8] = temp2;
+        fin[FIN_dth * 8] = dth;
+        fin[FIN_dqh * 8] = dqh;
+        fin[FIN_tlbef * 8] = tlbef;
+        fin[FIN_dt_veg * 8] = dt_veg;
+        fin[FIN_obu_trip * 8] = obu_trip;
+        fin[FIN_trips * 8] = (double)itlef;
+        fin[FIN_err * 8] = (double)err;
+        pos = -1;
       }
       PR_T(6)
 #if CF_PROBE >= 4
@@ -985,25 +1060,100 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 #endif
 }
 
-__global__ void k_cf_reset(const DevState* __restrict__ S)
+// =====================================================================================================
+// k_cf_finish - one thread per column, coalesced: compute_flux (canopy_fluxes_impl.hh:456-540) from the converged
+// iteration state, the 2 m profiles of the last trip (friction_velocity_temp2m / _humidity2m, :239-240), state writes.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ S, double dtime)
 {
-  if (threadIdx.x == 0) {
-    for (int k = LIST_CF_DAY_LONG; k <= LIST_CF_NIGHT; k++) {
-      ELMK_LIST_COUNT(S, k) = 0u;
-      ELMK_LIST_HEAD(S, k) = 0u;
-    }
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  if (blockIdx.x == 0 && threadIdx.x < CF_NCLS) CF_CLASS_COUNT(S, threadIdx.x) = 0u;  // for the next call's k_cf_count
+  if (S->land.lakpoi || c >= S->ncols) return;
+  const int32_t pos = S->cf_pos[c];
+  if (pos < 0) return;
+  CfFin f;
+  const double* __restrict__ fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
+#define X(n) f.n = fin[FIN_##n * 8];
+  CF_FIN_FIELDS(X)
+#undef X
+  const double t_veg = f.t_veg;
+  S->btran[c] = f.btran;
+  S->t_veg[c] = t_veg;
+  S->qflx_tran_veg[c] = f.qflx_tran_veg;
+  S->qflx_evap_veg[c] = f.qflx_evap_veg;
+  S->eflx_sh_veg[c] = f.eflx_sh_veg;
+  const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c];
+  const double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
+  const double thm = S->thm[c], t_grnd = S->t_grnd[c];
+  const int snl = S->snl[c];
+  const double t_soi0 = LV(t_soisno, NLEVSNO);
+  const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
+  const double wtg = f.wtg, wtl0 = f.wtl0, wta0 = f.wta0, wtal = f.wtal;
+  const double wtgq = f.wtgq, wtalq = f.wtalq, wtlq0 = f.wtlq0, wtaq0 = f.wtaq0, qsatl = f.qsatl;
+  const double delt = wtal * t_grnd - wtl0 * t_veg - wta0 * thm;
+  S->eflx_sh_grnd[c] = CPAIR * forc_rho * wtg * delt;
+  const double delt_snow = wtal * t_top - wtl0 * t_veg - wta0 * thm;
+  S->eflx_sh_snow[c] = CPAIR * forc_rho * wtg * delt_snow;
+  const double delt_soil = wtal * t_soi0 - wtl0 * t_veg - wta0 * thm;
+  S->eflx_sh_soil[c] = CPAIR * forc_rho * wtg * delt_soil;
+  const double delt_h2osfc = wtal * S->t_h2osfc[c] - wtl0 * t_veg - wta0 * thm;
+  S->eflx_sh_h2osfc[c] = CPAIR * forc_rho * wtg * delt_h2osfc;
+  S->qflx_evap_soi[c] = forc_rho * wtgq * f.delq;
+  const double delq_snow = wtalq * S->qg_snow[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+  S->qflx_ev_snow[c] = forc_rho * wtgq * delq_snow;
+  const double delq_soil = wtalq * S->qg_soil[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+  S->qflx_ev_soil[c] = forc_rho * wtgq * delq_soil;
+  const double delq_h2osfc = wtalq * S->qg_h2osfc[c] - wtlq0 * qsatl - wtaq0 * forc_q;
+  S->qflx_ev_h2osfc[c] = forc_rho * wtgq * delq_h2osfc;
+  // 2 m profiles of the last trip: z0hv == z0qv == z0mv here, so humidity2m takes temp2m's value (:153)
+  const double z0mv = S->z0mv[c];
+  const double temp12m = fv_profile<true>(2.0 + z0mv, f.obu_trip, z0mv);
+  const double temp22m = temp12m;
+  const double temp1 = f.temp1, temp2 = f.temp2;
+  const double t_ref2m = thm + temp1 * f.dth * (1.0 / temp12m - 1.0 / temp1);
+  const double q_ref2m = forc_q + temp2 * f.dqh * (1.0 / temp22m - 1.0 / temp2);
+  double e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT;
+  qsat(t_ref2m, forc_pbot, e_ref2m, de2mdT, qsat_ref2m, dqsat2mdT);
+  S->t_ref2m[c] = t_ref2m;
+  S->q_ref2m[c] = q_ref2m;
+  S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m) * 100.0);
+  const double emv = S->emv[c], emg = S->emg[c], forc_lwrad = S->forc_lwrad[c];
+  const double tlbef = f.tlbef, dt_veg = f.dt_veg;
+  const double lw_grnd = S->wk[(int64_t)WK_CF_LWGRND * ld + c];
+  S->dlrad[c] = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
+  S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * forc_lwrad +
+                 emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
+                 emg * (1.0 - emv) * STEBOL * lw_grnd);
+  double cgrnds = 0.0, cgrndl = 0.0;
+  cgrnds += CPAIR * forc_rho * wtg * wtal;
+  cgrndl += forc_rho * wtgq * wtalq * S->dqgdT[c];
+  S->cgrnds[c] = cgrnds;
+  S->cgrndl[c] = cgrndl;
+  S->cgrnd[c] = cgrnds + cgrndl * S->htvp[c];
+  S->h2ocan[c] = dmax(0.0, S->h2ocan[c] + (f.qflx_tran_veg - f.qflx_evap_veg) * dtime);
+  const uint32_t err = (uint32_t)f.err;
+  if (err) S->err_flags[c] |= err;
+  // low half: trips of this call (diagnostics); high half: scheduling hint = slowly decaying maximum of the trip
+  // count, so a column that needed many trips recently keeps being scheduled early even if its last call was short
+  {
+    const int trips = (int)f.trips;
+    const int decayed = (S->cf_niter[c] >> 16) - 1;
+    S->cf_niter[c] = ((trips > decayed ? trips : decayed) << 16) | trips;
   }
 }
 
 void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st)
 {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_cf_reset, dim3(1), dim3(64), 0, st, S);
-  hipLaunchKernelGGL(k_cf_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S);
-  // persistent: enough workgroups to fill every CU at the kernel's occupancy; surplus groups find empty queues
-  int64_t groups = (n + 255) / 256;
-  if (groups > 256 * 2) groups = 256 * 2;
-  hipLaunchKernelGGL(k_cf_iterate, dim3((unsigned)groups), dim3(256), 0, st, S, dt);
+  const unsigned nblk = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_cf_count, dim3(nblk), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S);
+  // persistent: one wave per SIMD is resident at this kernel's register footprint (256 workgroups); workgroups that
+  // start later find the queue empty
+  unsigned groups = nblk < 512u ? nblk : 512u;
+  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(256), 0, st, S, dt);
+  hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt);
 }
 
 }  // namespace elmk

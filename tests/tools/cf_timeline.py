@@ -12,20 +12,30 @@ from elmkernels_amd import state as st  # noqa: E402
 
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 D, _ = bench.build_state(cols, 0, "B", 0x5EEDE1A0)
-for _ in range(3):
+for _ in range(int(os.environ.get('CF_WARM', '2'))):
     D.restore_fields()
     st.timestep7(D, 1800.0)
+prev = D.canopy_trip_counts()
+D.restore_fields()
+st.timestep7(D, 1800.0)
 D.sync()
 trips = D.canopy_trip_counts()
+d = trips - prev
+print("trip count change between the last two steps: changed", int((d != 0).sum()), "|d|>5:", int((abs(d) > 5).sum()),
+      "hint<=5 but now >=12:", int(((prev <= 5) & (prev > 0) & (trips >= 12)).sum()), "max", int(abs(d).max()))
 veg = trips > 0
 day = (D.download("nrad") > 0) & ((D.download("parsun_z").reshape(cols, -1)[:, 0] > 0) | (D.download("parsha_z").reshape(cols, -1)[:, 0] > 0))
+for lo, hi in ((1, 5), (6, 8), (9, 11), (12, 15), (16, 21), (22, 41)):
+    for nm, mk in (("day", day), ("night", ~day)):
+        m = (prev >= lo) & (prev <= hi) & mk
+        print(f"prev {lo}-{hi} {nm}: n {int(m.sum())}  now>=12: {int((trips[m] >= 12).sum())}  now>=20: {int((trips[m] >= 20).sum())}  now>=30: {int((trips[m] >= 30).sum())}")
 print(f"columns {cols}: vegetated {veg.sum()} day {int((veg & day).sum())} night {int((veg & ~day).sum())}")
 for name, m in (("day", veg & day), ("night", veg & ~day)):
     t = trips[m]
     h = np.bincount(t, minlength=42)
     print(name, "mean trips %.2f" % t.mean(), "hist", {i: int(v) for i, v in enumerate(h) if v})
 ld = D.level_stride
-WK_DEBUG = 7
+WK_DEBUG = 1
 nw = 2048
 w = D.read_work(WK_DEBUG * ld, nw * 16).reshape(nw, 16)
 w = w[w[:, 7] == 1.0]
@@ -40,6 +50,8 @@ if len(w):
           f"lane utilisation over trips {w[busy, 4].sum() / (64 * w[busy, 3].sum()):.3f}; refills/wave {w[busy, 5].mean():.1f}; "
           f"us per trip {((end - start)[busy].sum() / w[busy, 3].sum()):.1f}")
     # utilisation before / after the queue ran dry is not separable per trip here; report the tail length instead
+    late = np.argsort(end)[-5:]
+    print("latest waves: end us", np.round(end[late]), "trips", w[late, 3], "cols", w[late, 6], "refills", w[late, 5])
     print(f"tail: last wave ends {end.max() - np.nanmin(exh):.0f} us after the queue ran dry (kernel {end.max():.0f} us)")
     sec = w[busy, 8:16].sum(axis=0)
     if sec.sum() > 0:

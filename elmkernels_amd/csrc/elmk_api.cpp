@@ -46,6 +46,7 @@ struct elmk_ctx {
   int dev = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  SideStreams side{};
   int64_t ncols = 0;
   int64_t ld = 0;
   DevState h;            // host mirror of the device parameter block
@@ -144,6 +145,12 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreate"))
     return fail(ELMK_E_HIP);
   ctx->stream = ctx->own_stream;
+  for (int i = 0; i < ELMK_NSIDE; i++) {
+    if (hip_fail(ctx, hipStreamCreateWithFlags(&ctx->side.s[i], hipStreamNonBlocking), "hipStreamCreate(side)") ||
+        hip_fail(ctx, hipEventCreateWithFlags(&ctx->side.join[i], hipEventDisableTiming), "hipEventCreate"))
+      return fail(ELMK_E_HIP);
+  }
+  if (hip_fail(ctx, hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming), "hipEventCreate")) return fail(ELMK_E_HIP);
 
   // arena layout
   size_t off = 0;
@@ -238,6 +245,14 @@ int elmk_destroy(elmk_ctx* ctx)
   if (ctx->red_or) (void)hipFree(ctx->red_or);
   if (ctx->staging) (void)hipFree(ctx->staging);
   for (char* b : ctx->snap_bufs) (void)hipFree(b);
+  for (int i = 0; i < ELMK_NSIDE; i++) {
+    if (ctx->side.s[i]) {
+      (void)hipStreamSynchronize(ctx->side.s[i]);
+      (void)hipStreamDestroy(ctx->side.s[i]);
+    }
+    if (ctx->side.join[i]) (void)hipEventDestroy(ctx->side.join[i]);
+  }
+  if (ctx->side.fork) (void)hipEventDestroy(ctx->side.fork);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ELMK_OK;
@@ -502,7 +517,7 @@ int elmk_frac_wet(elmk_ctx* ctx)
 int elmk_albedo_snicar(elmk_ctx* ctx)
 {
   PHYSICS_PROLOGUE();
-  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }
@@ -547,7 +562,7 @@ int elmk_timestep7(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
   launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
-  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
   launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
   launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
   launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
@@ -596,7 +611,7 @@ int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_k
     HIPCHK(hipEventRecord(e[0], ctx->stream));
     launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
     HIPCHK(hipEventRecord(e[1], ctx->stream));
-    launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream);
+    launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
     HIPCHK(hipEventRecord(e[2], ctx->stream));
     launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
     HIPCHK(hipEventRecord(e[3], ctx->stream));

@@ -10,9 +10,18 @@ namespace elmk {
 
 struct DevState;
 
+// side streams of a context: independent launches of one wrapper run beside each other (fork from / join to the
+// caller's stream with events, so the wrapper still behaves as one in-order operation on that stream)
+constexpr int ELMK_NSIDE = 5;
+struct SideStreams {
+  hipStream_t s[ELMK_NSIDE];
+  hipEvent_t fork;
+  hipEvent_t join[ELMK_NSIDE];
+};
+
 // the seven physics launches (one per reference L3 wrapper)
 void launch_frac_wet(const DevState* S, int64_t n, hipStream_t st);
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st);
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side);
 void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);

@@ -759,7 +759,7 @@ __global__ void k_alb_reset(const DevState* __restrict__ S)
   }
 }
 
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side)
 {
   if (n <= 0) return;
   const dim3 block(256);
@@ -767,12 +767,21 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st)
   const unsigned capped = full < 2048u ? full : 2048u;  // queue kernels are grid-stride over a device-side count
   hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
   hipLaunchKernelGGL(k_alb_main, dim3(full), block, 0, st, S);
-  hipLaunchKernelGGL(k_alb_snow<5>, dim3(capped), block, 0, st, S);  // longest work first
-  hipLaunchKernelGGL(k_alb_snow<4>, dim3(capped), block, 0, st, S);
-  hipLaunchKernelGGL(k_alb_snow<3>, dim3(capped), block, 0, st, S);
-  hipLaunchKernelGGL(k_alb_snow<2>, dim3(capped), block, 0, st, S);
-  hipLaunchKernelGGL(k_alb_snow<1>, dim3(capped), block, 0, st, S);
-  hipLaunchKernelGGL(k_alb_snow<0>, dim3(capped), block, 0, st, S);
+  // The six layer-count queues are independent, each is a latency-bound launch of about one wave per SIMD
+  // (the unrolled SNICAR state of NL layers takes 250-450 VGPRs), and each alone leaves the last round of waves
+  // mostly empty.  They run beside each other on side streams, so idle CUs of one fill with workgroups of another.
+  (void)hipEventRecord(side->fork, st);
+  for (int i = 0; i < ELMK_NSIDE; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
+  hipLaunchKernelGGL(k_alb_snow<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
+  hipLaunchKernelGGL(k_alb_snow<4>, dim3(capped), block, 0, side->s[0], S);
+  hipLaunchKernelGGL(k_alb_snow<3>, dim3(capped), block, 0, side->s[1], S);
+  hipLaunchKernelGGL(k_alb_snow<2>, dim3(capped), block, 0, side->s[2], S);
+  hipLaunchKernelGGL(k_alb_snow<1>, dim3(capped), block, 0, side->s[3], S);
+  hipLaunchKernelGGL(k_alb_snow<0>, dim3(capped), block, 0, side->s[4], S);
+  for (int i = 0; i < ELMK_NSIDE; i++) {
+    (void)hipEventRecord(side->join[i], side->s[i]);
+    (void)hipStreamWaitEvent(st, side->join[i], 0);
+  }
 }
 
 }  // namespace elmk

@@ -217,6 +217,9 @@ __device__ __forceinline__ void psn_hybrid(double x0, CiCtx& k)
     if (fabs(f1) <= eps1) break;
     if (f1 * f0 < 0.0) {
       (void)psn_brent(x0, x1, f0, f1, tol, k);
+#if CF_PROBE >= 4
+      k.err |= 0x80000000u;  // probe only: Brent was needed
+#endif
       break;
     }
     if (iter > itmax) {
@@ -450,29 +453,44 @@ __device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const La
   }
   // all day columns before the night ones: a day column can jump from a handful of trips to the 40-trip limit from
   // one call to the next (a few per 100000 do), a night column was never seen to; so a mispredicted long column
-  // still starts in the first half of the queue, and the end of the queue is reliably short work
+  // still starts in the first half of the queue, and the end of the queue is reliably short work.
+  // (Separating C3 from C4 columns as well - 24 classes - was measured: no gain, the finer classes cost as much in
+  // k_cf_init's scattered record writes and in queue tail as the C4 branches cost in mixed waves.)
   return (day ? 0 : CF_NCLS / 2) + bin;
 }
 
+// One workgroup counts CF_COUNT_TILES tiles of 256 columns (a tile = one workgroup of k_cf_init) and takes the
+// slices of all of them with ONE atomic per class: the class totals are 12 addresses, every atomic on them serialises.
+constexpr int CF_COUNT_TILES = 8;
 __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S)
 {
-  __shared__ uint32_t s_cnt[CF_NCLS];
-  if (threadIdx.x < CF_NCLS) s_cnt[threadIdx.x] = 0u;
+  __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];
+  for (int i = threadIdx.x; i < CF_COUNT_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
   __syncthreads();
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const Land L = S->land;
-  const int cls = L.lakpoi ? -1 : cf_class(S, L, c, c < S->ncols);
   const int lane = threadIdx.x & 63;
+  const int64_t tile0 = (int64_t)blockIdx.x * CF_COUNT_TILES;
+#pragma unroll 1
+  for (int t = 0; t < CF_COUNT_TILES; t++) {
+    const int64_t c = (tile0 + t) * 256 + threadIdx.x;
+    const int cls = L.lakpoi ? -1 : cf_class(S, L, c, c < S->ncols);
 #pragma unroll
-  for (int k = 0; k < CF_NCLS; k++) {
-    const unsigned long long m = __ballot(cls == k);
-    if (lane == 0 && m) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+    for (int k = 0; k < CF_NCLS; k++) {
+      const unsigned long long m = __ballot(cls == k);
+      if (lane == 0 && m) atomicAdd(&s_cnt[t][k], (uint32_t)__popcll(m));
+    }
   }
   __syncthreads();
-  // this workgroup's slice of class k: [returned value, + count) relative to the start of the class
+  // tile t's slice of class k: [value stored, + its count) relative to the start of the class
   if (threadIdx.x < CF_NCLS) {
-    const uint32_t n = s_cnt[threadIdx.x];
-    S->cf_blk[(int64_t)threadIdx.x * S->cf_nblk + blockIdx.x] = n ? atomicAdd(&CF_CLASS_COUNT(S, threadIdx.x), n) : 0u;
+    const int k = threadIdx.x;
+    uint32_t n = 0u;
+    for (int t = 0; t < CF_COUNT_TILES; t++) n += s_cnt[t][k];
+    uint32_t base = n ? atomicAdd(&CF_CLASS_COUNT(S, k), n) : 0u;
+    for (int t = 0; t < CF_COUNT_TILES; t++) {
+      if (tile0 + t < S->cf_nblk) S->cf_blk[(int64_t)k * S->cf_nblk + tile0 + t] = base;
+      base += s_cnt[t][k];
+    }
   }
 }
 
@@ -534,7 +552,10 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   }
   if (!veg) return;
 
+  // record fields are stored as soon as they are final (PUT), so few of them are live at any time
   CfRec r;
+  double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
+#define PUT(n) rec[REC_##n * 8] = r.n;
   const int snl = S->snl[c];
   const int vtype = S->vtype[c];
   const double* __restrict__ P = S->pft_psn[vtype];
@@ -578,12 +599,16 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   }
   S->btran[c] = btran;
   r.btran = btran;
+  PUT(btran)
   const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
 
   // canopy roughness blend (canopy_fluxes_impl.hh:141-147)
   r.elai = S->elai[c];
+  PUT(elai)
   r.esai = S->esai[c];
+  PUT(esai)
   r.z0mg = S->z0mg[c];
+  PUT(z0mg)
   const double tlsai_crit = 2.0;
   const double lt = dmin(r.elai + r.esai, tlsai_crit);
   const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
@@ -596,36 +621,62 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   S->z0hv[c] = z0mv;
   S->z0qv[c] = z0mv;
   r.displa = displa;
+  PUT(displa)
   r.z0mv = z0mv;
+  PUT(z0mv)
 
   // forcing, derived forcing (atm_physics_impl.hh:246-272) and the wrapper-level inputs of the iteration
   r.forc_pbot = S->forc_pbot[c];
+  PUT(forc_pbot)
   r.forc_q = S->forc_qbot[c];
+  PUT(forc_q)
   r.forc_th = S->forc_thbot[c];
+  PUT(forc_th)
   r.forc_rho = derive_forc_rho(r.forc_pbot, r.forc_q, S->forc_tbot[c]);
+  PUT(forc_rho)
   r.thm = S->thm[c];
+  PUT(thm)
   r.thv = S->thv[c];
+  PUT(thv)
   r.qg = S->qg[c];
+  PUT(qg)
   r.t_grnd = S->t_grnd[c];
+  PUT(t_grnd)
   r.hgt_u = S->forc_hgt_u_patch[c];
+  PUT(hgt_u)
   r.hgt_t = S->forc_hgt_t_patch[c];
+  PUT(hgt_t)
   r.hgt_q = S->forc_hgt_q_patch[c];
+  PUT(hgt_q)
   const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
   r.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
+  PUT(ur)
   r.htop = S->htop[c];
+  PUT(htop)
   r.fwet = S->fwet[c];
+  PUT(fwet)
   r.fdry = S->fdry[c];
+  PUT(fdry)
   r.laisun = S->laisun[c];
+  PUT(laisun)
   r.laisha = S->laisha[c];
+  PUT(laisha)
   r.soilbeta = S->soilbeta[c];
+  PUT(soilbeta)
   r.sabv = S->sabv[c];
+  PUT(sabv)
   r.h2ocan = S->h2ocan[c];
+  PUT(h2ocan)
   const double emv = S->emv[c], emg = S->emg[c];
   r.air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * S->forc_lwrad[c];  // :360-362
   r.bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
+  PUT(air) PUT(bir)
   r.cir = emv * emg * STEBOL;
+  PUT(cir)
   r.vcmaxcintsun = S->vcmaxcintsun[c];
+  PUT(vcmaxcintsun)
   r.vcmaxcintsha = S->vcmaxcintsha[c];
+  PUT(vcmaxcintsha)
   const int nrad = S->nrad[c];
   r.parsun = r.parsha = r.lai_sun_z = r.lai_sha_z = 0.0;
   if (nrad > 0) {
@@ -634,15 +685,19 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     r.lai_sun_z = S->laisun_z[c];
     r.lai_sha_z = S->laisha_z[c];
   }
+  PUT(parsun) PUT(parsha) PUT(lai_sun_z) PUT(lai_sha_z)
   // loop-invariant sub-expressions of the iteration body (:272, :301-303, :270)
   r.w_lai = exp(-(r.elai + r.esai));
+  PUT(w_lai)
   {
     const double snow_depth_c = 0.05;
     const double fsno_dl = S->snow_depth[c] / snow_depth_c;
     const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
     r.rdl_num = (1.0 - exp(-elai_dl));
+    PUT(rdl_num)
   }
   r.sqrt_dleaf = sqrt(P[P_dleaf]);
+  PUT(sqrt_dleaf)
 
   // initial flux profile and Monin-Obukhov length (:158-181)
   {
@@ -654,12 +709,14 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     const double zldis = r.hgt_u - displa;
     if (!(zldis >= 0.0)) S->err_flags[c] |= ELMK_ERR_CANFLX_FORC_HGT;
     monin_obukhov_length(r.ur, r.thv, dthv, zldis, z0mv, r.um, r.obu);
+    PUT(um) PUT(obu)
   }
 
   // ground-emitted longwave (:366-367), loop-invariant
   const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
   r.lw_grnd = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
                frac_h2osfc * pow(S->t_h2osfc[c], 4.0));
+  PUT(lw_grnd)
   S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
 
   // iteration-invariant part of photosynthesis() (photosynthesis_impl.hh:22-61, :91, :109-114, :135, :152-154)
@@ -673,36 +730,52 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
     vcmax25top *= P[P_fnitr];
     r.vcmax25top = vcmax25top;
+    PUT(vcmax25top)
     r.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
+    PUT(jmax25top)
     r.tpu25top = 0.167 * vcmax25top;
+    PUT(tpu25top)
     r.kp25top = 20000.0 * vcmax25top;
+    PUT(kp25top)
     r.lmr25top = c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
+    PUT(lmr25top)
     r.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    PUT(vcmaxse)
     r.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
+    PUT(jmaxse)
     r.vcmaxc = psn_fth25(P[P_vcmaxhd], r.vcmaxse);
+    PUT(vcmaxc)
     r.jmaxc = psn_fth25(P[P_jmaxhd], r.jmaxse);
+    PUT(jmaxc)
     r.tpuc = psn_fth25(P[P_tpuhd], r.vcmaxse);
+    PUT(tpuc)
     r.lmrc = psn_fth25(P[P_lmrhd], P[P_lmrse]);
+    PUT(lmrc)
     r.cf = r.forc_pbot / (RGAS * 1.0e-3 * r.thm) * 1.e06;
+    PUT(cf)
     const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
     r.cp25 = 0.5 * derive_forc_po2(r.forc_pbot) / sco;
+    PUT(cp25)
     r.qe = P[P_qe];
+    PUT(qe)
     r.theta_cj = P[P_theta_cj];
+    PUT(theta_cj)
     r.bbbopt = P[P_bbbopt];
+    PUT(bbbopt)
     r.mbbopt = P[P_mbbopt];
+    PUT(mbbopt)
   }
 
   // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
   r.t_veg = S->t_veg[c];
+  PUT(t_veg)
   {
     double deldT;
     qsat(r.t_veg, r.forc_pbot, r.el, deldT, r.qsatl, r.qsatldT);
+    PUT(el) PUT(qsatl) PUT(qsatldT)
   }
 
-  double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
-#define X(n) rec[REC_##n * 8] = r.n;
-  CF_REC_FIELDS(X)
-#undef X
+#undef PUT
   int32_t* __restrict__ irec = S->cf_irec + pos;
   irec[(int64_t)IREC_vtype * ld] = vtype;
   irec[(int64_t)IREC_nrad * ld] = nrad;
@@ -744,7 +817,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   int itlef = 0, nmozsgn = 0;
 #if CF_PROBE >= 4  // per-wave timeline: start, queue-exhausted and end time (100 MHz ticks), trips, active lane-trips
   const uint64_t pr_t0 = wall_clock64();
-  uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0;
+  uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0, pr_brent = 0, pr_brent_trips = 0, pr_c4 = 0, pr_day = 0;
 #endif
 #if CF_PROBE == 5  // shader-clock cycles per section of the loop (wave-uniform accumulators)
   uint64_t pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -891,6 +964,13 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double rssha = psn_phase(I, T, nrad, in.forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, in.vcmaxcintsha,
                                      in.parsha, in.lai_sha_z, err);
       PR_T(4)
+#if CF_PROBE >= 4
+      pr_brent += (uint64_t)__popcll(__ballot((err & 0x80000000u) != 0u));
+      pr_brent_trips += (__ballot((err & 0x80000000u) != 0u) != 0ull) ? 1u : 0u;
+      pr_c4 += (__ballot(!I.c3flag) != 0ull) ? 1u : 0u;
+      pr_day += (uint64_t)__popcll(__ballot(day));
+      err &= 0x7FFFFFFFu;
+#endif
 
       const double wta = 1.0 / rah0;
       const double wtl = (in.elai + in.esai) / rb;
@@ -949,8 +1029,9 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         efe = 0.1 * efeold;
         erre = efe - efeold;
       }
+      const double tveg3 = pow(t_veg, 3.0);  // t_veg == tlbef here: also the pow(tlbef, 3.0) of errv below (:399)
       dt_veg = (in.sabv + in.air + in.bir * pow(t_veg, 4.0) + in.cir * in.lw_grnd - efsh - efe) /
-               (-4.0 * in.bir * pow(t_veg, 3.0) + dc1 * wtga + dc2 * wtgaq * qsatldT);
+               (-4.0 * in.bir * tveg3 + dc1 * wtga + dc2 * wtgaq * qsatldT);
       t_veg = tlbef + dt_veg;
       const double dels = dt_veg;
       del = fabs(dels);
@@ -958,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       if (del > 1.0) {
         dt_veg = dels / del;
         t_veg = tlbef + dt_veg;
-        errv = in.sabv + in.air + in.bir * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) + in.cir * in.lw_grnd -
+        errv = in.sabv + in.air + in.bir * tveg3 * (tlbef + 4.0 * dt_veg) + in.cir * in.lw_grnd -
                (efsh + dc1 * wtga * dt_veg) - (efe + dc2 * wtgaq * qsatldT * dt_veg);
       }
       efpot = in.forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * in.qg - wtaq0 * in.forc_q);
@@ -1046,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   if (lane == 0) {
     double* o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
 #if CF_PROBE == 5
-    for (int i = 0; i < 8; i++) o[8 + i] = (double)pr_acc[i];
+    for (int i = 0; i < 4; i++) o[8 + i] = (double)(pr_acc[2 * i] + pr_acc[2 * i + 1]);
 #endif
     o[0] = (double)pr_t0;
     o[1] = (double)pr_texh;
@@ -1056,6 +1137,10 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
     o[5] = (double)pr_refills;
     o[6] = (double)pr_cols;
     o[7] = 1.0;
+    o[15] = (double)pr_brent;
+    o[14] = (double)pr_brent_trips;
+    o[13] = (double)pr_c4;
+    o[12] = (double)pr_day;
   }
 #endif
 }
@@ -1147,7 +1232,7 @@ void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t s
 {
   if (n <= 0) return;
   const unsigned nblk = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_cf_count, dim3(nblk), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_cf_count, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S);
   hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S);
   // persistent: one wave per SIMD is resident at this kernel's register footprint (256 workgroups); workgroups that
   // start later find the queue empty

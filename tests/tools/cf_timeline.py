@@ -53,9 +53,11 @@ if len(w):
     late = np.argsort(end)[-5:]
     print("latest waves: end us", np.round(end[late]), "trips", w[late, 3], "cols", w[late, 6], "refills", w[late, 5])
     print(f"tail: last wave ends {end.max() - np.nanmin(exh):.0f} us after the queue ran dry (kernel {end.max():.0f} us)")
-    sec = w[busy, 8:16].sum(axis=0)
+    print(f"lane-trips {w[busy, 4].sum():.0f}: day {w[busy, 12].sum() / w[busy, 4].sum():.3f}; Brent used in {w[busy, 15].sum() / w[busy, 4].sum():.4f} of lane-trips, "
+          f"{w[busy, 14].sum() / w[busy, 3].sum():.3f} of wave-trips; wave-trips with a C4 lane {w[busy, 13].sum() / w[busy, 3].sum():.3f}")
+    sec = w[busy, 8:12].sum(axis=0)
     if sec.sum() > 0:
-        names = ["refill+setup", "friction", "resistances+psn_temp", "psn sun", "psn shade", "energy balance", "epilogue", "-"]
+        names = ["refill+setup+friction", "resistances+psn_temp+psn sun", "psn shade+energy balance", "epilogue"]
         print("shader-clock share per section:", {n: round(float(v / sec.sum()), 3) for n, v in zip(names, sec) if n != "-"},
               "cycles/trip", round(float(sec.sum() / w[busy, 3].sum())))
 else:

@@ -103,7 +103,7 @@ SUB_KERNELS = {
     "surface_radiation": ["elmk::k_surface_radiation"],
     "canopy_temperature": ["elmk::k_canopy_temperature"],
     "bareground_fluxes": ["elmk::k_bg_main", "elmk::k_bg_flux"],
-    "canopy_fluxes": ["elmk::k_cf_init", "elmk::k_cf_iterate"],
+    "canopy_fluxes": ["elmk::k_cf_count", "elmk::k_cf_init", "elmk::k_cf_iterate", "elmk::k_cf_finish"],
 }
 
 

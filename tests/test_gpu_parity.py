@@ -188,3 +188,99 @@ def test_tiling_invariance_at_scale():
     fl, _ = big.error_summary()
     assert fb == fl
     Dbase.close(); big.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 257, 1000])
+def test_ragged_sizes(n):
+    """Column counts that are not multiples of the wave (64) or workgroup (256) size: the padded tail of every level
+    row must neither be read into results nor written (queue positions, record blocks of 8, work lists)."""
+    D, S = _pair(n, "B", 40 + n)
+    for step in range(2):  # the second step runs with scheduling hints from the first
+        st.timestep7(D, DT)
+        S.timestep7(DT)
+        assert D.ncols == n and D["t_veg"].shape == (n,)
+        _check(D, S, f"n={n} step {step}")
+        for k, v in S.fields.items():  # re-sync (rounding differences are not carried into the next step)
+            if k != "err_flags":
+                D[k] = v
+    D.close()
+
+
+def _uniform_case(mutate, n=3000, seed=77):
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier="B", seed=seed)
+    mutate(cols)
+    S = H.oracle_state(cols, scal, soil)
+    D = H.device_state(cols, scal, soil)
+    return D, S
+
+
+def test_all_night_all_bare_all_deep_snow():
+    """Degenerate populations: every work list but one is empty (queue kernels see counts of 0 and of ncols)."""
+    def night(c):
+        c["coszen"][:] = -0.3
+    def bare(c):
+        c["frac_veg_nosno"][:] = 0
+    def noon(c):
+        c["coszen"][:] = 0.9
+    for name, mut in (("night", night), ("bare", bare), ("noon", noon)):
+        D, S = _uniform_case(mut)
+        st.timestep7(D, DT)
+        S.timestep7(DT)
+        _check(D, S, f"uniform population: {name}")
+        trips = D.canopy_trip_counts()
+        veg = S["frac_veg_nosno"] != 0
+        assert ((trips > 0) == veg).all() and trips.max() <= 41
+        D.close()
+
+
+def test_error_flags_match_the_reference_throw_sites():
+    """Inputs that make the reference throw/assert: the device raises the same per-column bits as the oracle and
+    leaves the other columns' results untouched."""
+    ft = st.field_table()
+    n = 2048
+    cols, scal, soil = synth.make_state(ft, n, tier="B", seed=91)
+    rng = np.random.default_rng(5)
+    bad_rds = rng.choice(n, 200, replace=False)
+    cols["snw_rds"][bad_rds] = 5000.0  # beyond the Mie table: snow_snicar_impl.hh:74-78 throws
+    bad_hgt = rng.choice(n, 200, replace=False)
+    for k in ("forc_hgt_u_patch", "forc_hgt_t_patch", "forc_hgt_q_patch"):
+        cols[k][bad_hgt] = -50.0  # still below the displacement height after canopy_temperature's "+= z0m + displa":
+        #                           canopy_fluxes_impl.hh:178 assert
+    S = H.oracle_state(cols, scal, soil)
+    D = H.device_state(cols, scal, soil)
+    st.timestep7(D, DT)
+    S.timestep7(DT)
+    fd, fo = D["err_flags"] & 0x7FF, S["err_flags"] & 0x7FF
+    assert np.array_equal(fd, fo)
+    # the cases above did reach their throw sites (only sunlit snowy / vegetated columns can)
+    assert ((fo & (1 << 6)) != 0).sum() >= 20 and ((fo & (1 << 1)) != 0).sum() >= 20
+    flags, first = D.error_summary()
+    assert flags & 0x7FF == int(np.bitwise_or.reduce(fo)) and first == int(np.nonzero(fo)[0][0])
+    _check(D, S, "columns without a fatal flag", skip_cols=fo != 0)
+    D.clear_errors()
+    assert D.error_summary()[0] == 0
+    D.close()
+
+
+def test_results_do_not_depend_on_the_schedule():
+    """The canopy_fluxes work queue is ordered by the previous call's trip counts (a hint) and filled in workgroup
+    arrival order: results must be bit-identical whatever the hint state and the order."""
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, 30000, tier="B", seed=123)
+    D = H.device_state(cols, scal, soil)
+    outs = []
+    for rep in range(3):  # rep 0: no hints; rep 1: exact hints; rep 2: hints from a different state
+        for k, v in cols.items():
+            D[k] = v
+        if rep == 2:
+            D["t_veg"] = cols["t_veg"] + 3.0
+            st.timestep7(D, DT)
+            for k, v in cols.items():
+                D[k] = v
+        st.timestep7(D, DT)
+        outs.append({k: D[k] for k in ("t_veg", "cgrnd", "h2ocan", "eflx_sh_veg", "t_ref2m", "albd", "flx_absdv", "sabg_lyr")})
+    for rep in (1, 2):
+        for k, v in outs[0].items():
+            assert np.array_equal(v, outs[rep][k], equal_nan=True), (rep, k)
+    D.close()

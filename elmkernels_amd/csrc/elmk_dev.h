@@ -102,7 +102,7 @@ enum : int {
 enum : int {
   LIST_CF_QUEUE = 0,  // canopy_fluxes work queue: only its length and head counters are used (k_canopy_fluxes.hip)
   LIST_BG,            // bare-ground columns
-  LIST_ALB_0,         // sunlit snow-free columns (soil albedo + canopy two-stream only)
+  LIST_ALB_0,         // (unused slot: snow-free columns need no queue)
   LIST_ALB_1,         // sunlit snow-covered columns by number of (possibly fictitious) snow layers 1..5
   LIST_ALB_2,
   LIST_ALB_3,
@@ -174,6 +174,7 @@ struct DevState {
   double* wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
   int32_t* lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
   uint32_t* counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
+  double* alb_snow;    // 28 x ld: SNICAR products of the sunlit snow-covered columns (k_albedo_snicar.hip), by column
   int32_t* cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
   double* cf_rec;      // CF_REC_N x ld: inputs of the queued columns, by queue position
   double* cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position

@@ -5,21 +5,22 @@
 //   snow_snicar::init_timestep :9, snow_aerosol_mie_params :107, snow_radiative_transfer_solver :313,
 //   snow_albedo_radiation_factor :673, run twice (direct, diffuse)   (src/physics/snow_snicar_impl.hh)
 //
-// Two stages.  k_alb_main (one thread per column, coalesced) finishes every column that needs no snow radiative
-// transfer - night columns (init_timestep defaults only) and sunlit snow-free columns (soil albedo + canopy
-// two-stream) - and queues the sunlit snow-covered columns by their number of snow layers.  k_alb_snow<NL> then
-// drains the NL-layer queue with the layer loops fully unrolled for exactly NL layers, so a wave never carries
-// lanes with different layer counts (SNICAR cost is proportional to NL: 10 band-passes x NL Delta-Eddington
-// layer solves with an 8-point Gauss quadrature each).
+// Three stages.
+//   k_alb_classify (one thread per column, coalesced): canopy_layer_lai, soil albedo of the sunlit columns, and the
+//     sunlit snow-covered columns queued by their number of snow layers NL.
+//   k_alb_snicar<NL> (queue-driven): the ten independent (pass, band) solves of a column - direct / diffuse x five
+//     spectral bands, each the Mie/aerosol mixing and the Delta-Eddington adding-doubling solve of NL layers with an
+//     8-point Gauss quadrature - run on ten lanes, six columns per wave; layer loops are compile-time (template NL),
+//     so every per-layer array is statically indexed and lives in registers, and a wave never carries lanes with
+//     different layer counts.  The band results are combined across the lanes in the reference's summation order
+//     (snow_snicar_impl.hh:724-741) and the two SnowOut of the column go to a scratch array.  One lane holds one
+//     band's state (165-280 VGPRs, two waves per SIMD) instead of a whole column's (250-450, one wave per SIMD).
+//     The five NL queues are independent launches and run beside each other on side streams.
+//   k_alb_final (one thread per column, coalesced): the init_timestep defaults of the night columns; for sunlit
+//     columns ground_albedo, flux_absorption_factor and the canopy two-stream solution.  Every output is written once.
 // The ~210 doubles of per-column scratch that the wrapper allocates as zero-filled Views on every call
-// (albedo_kokkos.cc:19-38) never touch memory here:
-//   * the Mie/aerosol mixing of a band and the Delta-Eddington adding-doubling solve of the same band are
-//     fused, so g_star/omega_star/tau_star shrink from [5][5] to one band of 5 layers;
-//   * the per-band absorbed fluxes flx_abs_lcl[6][5] are folded into the VIS value and the running
-//     flux-weighted NIR sum as each band finishes (same summation order as :724-741);
-//   * layer loops are compile-time (template NL), every per-layer array is statically indexed and lives in registers.
-// Night columns (coszen <= 0) only write the init_timestep defaults.  Lookup tables (Mie [3][5][1471] x2,
-// BC, aerosol) sit in one 355 KB device buffer that stays L2-resident; the gather index is round(snw_rds)-30.
+// (albedo_kokkos.cc:19-38) shrink to 28 (the SNICAR products).  Lookup tables (Mie [3][5][1471] x2, BC, aerosol) sit
+// in one 355 KB device buffer that stays L2-resident; the gather index is round(snw_rds)-30.
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 
@@ -39,269 +40,291 @@ struct SnowOut {
   double fabs_[6][2];    // flx_abs(i, {VIS, NIR})
 };
 
-// One SNICAR pass (flg_slr_in = 1 direct / 2 diffuse) for an active column (coszen > 0, h2osno > min_snw).
-// rds[] = snw_rds_lcl, ice[]/liq[] = h2osoi_*_lcl, mss[i][j] = mss_cnc_aer_in_fdb, snl_top in 0..4.
-template <int FLG, int NL>
-__device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, double mu_not,
-                                            const int (&rds)[5], const double (&ice)[5], const double (&liq)[5],
-                                            const double (&mss_in)[5][8], const double (&albsoi)[2], SnowOut& out,
-                                            uint32_t& err)
+// One (pass, band) of SNICAR for an active column (coszen > 0, h2osno > min_snw) with NL (possibly fictitious) snow
+// layers: snow_aerosol_mie_params (snow_snicar_impl.hh:107-305) and snow_radiative_transfer_solver (:313-667) of
+// that band.  pass 0 = direct beam (flg_slr_in 1), 1 = diffuse (2).  Returns the band albedo and fl[i] = absorbed flux
+// of layer i (i >= 5 - NL) and of the ground (fl[5]), after the reference's underflow clamp.
+// The ten (pass, band) solves of a column are independent until snow_albedo_radiation_factor sums the bands, so they
+// run on ten lanes; one lane then holds only one band of per-layer state (~150 VGPRs instead of 250-450 for a whole
+// column), which lets three waves share a SIMD and hide the latency of the long dependent fp64 chains.
+template <int NL>
+__device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int pass,
+                                            const int bnd, const double mu_not, const int snl, const double h2osno,
+                                            const double albsoi_b, double& albedo, double (&fl)[6], uint32_t& err)
 {
   constexpr int snl_top = 5 - NL;
+  const double* __restrict__ tab = S->snicar;
   const double difgauspt[8] = {0.9894009, 0.9445750, 0.8656312, 0.7554044, 0.6178762, 0.4580168, 0.2816036, 0.0950125};
   const double difgauswt[8] = {0.0271525, 0.0622535, 0.0951585, 0.1246290, 0.1495960, 0.1691565, 0.1826034, 0.1894506};
   const double puny = 1.0e-11;
   const double c0 = 0.0, c1 = 1.0, c3 = 3.0, c4 = 4.0, cp5 = 0.5, cp75 = 0.75, c1p5 = 1.5, trmin = 0.001;
-  // 5-band flux weights (snow_snicar_impl.hh:710-723)
-  const double w1 = (FLG == 1) ? 0.49352158521175 : 0.58581507618433;
-  const double w2 = (FLG == 1) ? 0.18099494230665 : 0.20156903770812;
-  const double w3 = (FLG == 1) ? 0.12094898498813 : 0.10917889346386;
-  const double w4 = (FLG == 1) ? 0.20453448749347 : 0.10343699264369;
-  const double flx_wgt[5] = {1.0, w1, w2, w3, w4};
   // incident irradiance (:88-98)
-  const double flx_slrd = (FLG == 1) ? 1.0 / (mu_not * ELM_PI) : 0.0;
-  const double flx_slri = (FLG == 1) ? 0.0 : 1.0;
+  const double flx_slrd = (pass == 0) ? 1.0 / (mu_not * ELM_PI) : 0.0;
+  const double flx_slri = (pass == 0) ? 0.0 : 1.0;
+  const double* __restrict__ tsnw = tab + ((pass == 0) ? SN_SNW_DRC : SN_SNW_DFS);
 
-  double mss[5][8];
+  // aerosol species 2..7 of this band (:179-210); species 0/1 (BC) depend on the layer
+  double ss_aer[8], asm_aer[8], ext_aer[8];
 #pragma unroll
-  for (int i = 0; i < 5; i++)
+  for (int s = 0; s < 6; s++) {
+    ss_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 0 + bnd];
+    asm_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 5 + bnd];
+    ext_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 10 + bnd];
+  }
+  // ---- snow_aerosol_mie_params for this band: delta-transformed layer optics (:215-305)
+  double g_star[5], omega_star[5], tau_star[5];
 #pragma unroll
-    for (int j = 0; j < 8; j++) mss[i][j] = mss_in[i][j];
+  for (int i = 0; i < 5; i++) {
+    g_star[i] = omega_star[i] = tau_star[i] = 0.0;
+    if (i >= snl_top) {
+      // local copies of the layer (snow_snicar::init_timestep :9-60); snl == 0 is the fictitious fresh-snow layer
+      double ice_i, liq_i;
+      int rds_i;
+      if (snl == 0) {  // only possible for NL == 1
+        ice_i = h2osno;
+        liq_i = 0.0;
+        rds_i = (int)round(SNW_RDS_MIN);
+      } else {
+        liq_i = LV(h2osoi_liq, i);
+        ice_i = LV(h2osoi_ice, i);
+        rds_i = (int)round(LV(snw_rds, i));
+      }
+      if (rds_i < SN_RDS_MIN_TBL || rds_i > SN_RDS_MAX_TBL) {
+        err |= ELMK_ERR_SNICAR_RDS;  // the reference throws (:74-78); clamp so the table gather stays in range
+        rds_i = rds_i < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : SN_RDS_MAX_TBL;
+      }
+      // aerosol mass concentrations (surface_albedo_impl.hh:141-150): OC species 2,3 are ignored; bands 3 and 4 see
+      // no aerosol (:150-156)
+      double mss[8];
+      mss[0] = LV(cnc_bcphi, i);
+      mss[1] = LV(cnc_bcpho, i);
+      mss[2] = 0.0;
+      mss[3] = 0.0;
+      mss[4] = LV(cnc_dst1, i);
+      mss[5] = LV(cnc_dst2, i);
+      mss[6] = LV(cnc_dst3, i);
+      mss[7] = LV(cnc_dst4, i);
+      if (bnd == 4 || bnd == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) mss[j] = 0.0;
+      }
+      const int rds_idx = rds_i - SN_RDS_MIN_TBL;
+      const double ss_snw = tsnw[(0 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+      const double asm_snw = tsnw[(1 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+      const double ext_snw = tsnw[(2 * 5 + bnd) * ELMK_MIE_N + rds_idx];
+      int idx_ice;
+      if (rds_i < 125) {
+        const double tmp1 = rds_i / 50;  // integer division as in the reference (:250)
+        idx_ice = (int)round(tmp1) - 1;
+      } else if (rds_i < 175) {
+        idx_ice = 1;
+      } else {
+        const double tmp1 = (rds_i / 250) + 2;  // integer division (:255)
+        idx_ice = (int)round(tmp1) - 1;
+      }
+      const int idx_ncl = 1;  // round(100/50) - 1 for both within-ice and external BC (:260-261), inside [0, 9]
+      if (idx_ice < 0) idx_ice = 0;
+      if (idx_ice > 7) idx_ice = 7;
+      const double enh_fct = tab[SN_BCENH + (idx_ice * 10 + idx_ncl) * 5 + bnd];
+      ss_aer[0] = tab[SN_BC1 + 0 + idx_ncl * 5 + bnd];
+      asm_aer[0] = tab[SN_BC1 + 50 + idx_ncl * 5 + bnd];
+      ext_aer[0] = tab[SN_BC1 + 100 + idx_ncl * 5 + bnd] * enh_fct;
+      ss_aer[1] = tab[SN_BC2 + 0 + idx_ncl * 5 + bnd];
+      asm_aer[1] = tab[SN_BC2 + 50 + idx_ncl * 5 + bnd];
+      ext_aer[1] = tab[SN_BC2 + 100 + idx_ncl * 5 + bnd];
 
-  double alb_nir_sum = 0.0, wgt_sum = 0.0;
-  double nir_sum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const double L_snw = ice_i + liq_i;
+      const double tau_snw = L_snw * ext_snw;
+      double tau_sum = 0.0, omega_sum = 0.0, g_sum = 0.0;
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    out.fabs_[i][0] = 0.0;  // flx_abs_lcl(i,0) is zero wherever the solver does not write (i < snl_top)
-    out.fabs_[i][1] = 0.0;
+      for (int j = 0; j < 8; ++j) {
+        const double L_aer = L_snw * mss[j];
+        const double tau_aer = L_aer * ext_aer[j];
+        tau_sum += tau_aer;
+        omega_sum += (tau_aer * ss_aer[j]);
+        g_sum += (tau_aer * ss_aer[j] * asm_aer[j]);
+      }
+      const double tau = tau_sum + tau_snw;
+      const double omega = (1.0 / tau) * (omega_sum + (ss_snw * tau_snw));
+      const double g = (1.0 / (tau * omega)) * (g_sum + (asm_snw * ss_snw * tau_snw));
+      g_star[i] = g / (1.0 + g);
+      omega_star[i] = ((1.0 - pow(g, 2.0)) * omega) / (1.0 - (omega * pow(g, 2.0)));
+      tau_star[i] = (1.0 - (omega * pow(g, 2.0))) * tau;
+    }
   }
 
-  const double* tsnw = tab + ((FLG == 1) ? SN_SNW_DRC : SN_SNW_DFS);
-
-#pragma unroll 1
-  for (int bnd = 0; bnd < 5; ++bnd) {
-    if (bnd == 4 || bnd == 3) {  // (:150-156)
+  // ---- snow_radiative_transfer_solver for this band (:384-667)
+  double trndir[6], trntdr[6], trndif[6], rdndif[6];
+  double rdir[5], rdif_a[5], tdir[5], tdif_a[5], trnlay[5];  // rdif_b == rdif_a, tdif_b == tdif_a (:489-490)
 #pragma unroll
-      for (int i = 0; i < 5; i++)
+  for (int i = 0; i < 6; i++) {
+    trndir[i] = c0;
+    trntdr[i] = c0;
+    trndif[i] = c0;
+    rdndif[i] = c0;
+  }
 #pragma unroll
-        for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
-    }
-    // aerosol species 2..7 of this band (:179-210); species 0/1 (BC) depend on the layer
-    double ss_aer[8], asm_aer[8], ext_aer[8];
-#pragma unroll
-    for (int s = 0; s < 6; s++) {
-      ss_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 0 + bnd];
-      asm_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 5 + bnd];
-      ext_aer[2 + s] = tab[SN_OC1 + s * SN_AER_STRIDE + 10 + bnd];
-    }
-    // ---- snow_aerosol_mie_params for this band: delta-transformed layer optics (:215-305)
-    double g_star[5], omega_star[5], tau_star[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      g_star[i] = omega_star[i] = tau_star[i] = 0.0;
-      if (i >= snl_top) {
-        const int rds_idx = rds[i] - SN_RDS_MIN_TBL;
-        const double ss_snw = tsnw[(0 * 5 + bnd) * ELMK_MIE_N + rds_idx];
-        const double asm_snw = tsnw[(1 * 5 + bnd) * ELMK_MIE_N + rds_idx];
-        const double ext_snw = tsnw[(2 * 5 + bnd) * ELMK_MIE_N + rds_idx];
-        int idx_ice;
-        if (rds[i] < 125) {
-          const double tmp1 = rds[i] / 50;  // integer division as in the reference (:250)
-          idx_ice = (int)round(tmp1) - 1;
-        } else if (rds[i] < 175) {
-          idx_ice = 1;
-        } else {
-          const double tmp1 = (rds[i] / 250) + 2;  // integer division (:255)
-          idx_ice = (int)round(tmp1) - 1;
-        }
-        const int idx_ncl = 1;  // round(100/50) - 1 for both within-ice and external BC (:260-261), inside [0, 9]
-        if (idx_ice < 0) idx_ice = 0;
-        if (idx_ice > 7) idx_ice = 7;
-        const double enh_fct = tab[SN_BCENH + (idx_ice * 10 + idx_ncl) * 5 + bnd];
-        ss_aer[0] = tab[SN_BC1 + 0 + idx_ncl * 5 + bnd];
-        asm_aer[0] = tab[SN_BC1 + 50 + idx_ncl * 5 + bnd];
-        ext_aer[0] = tab[SN_BC1 + 100 + idx_ncl * 5 + bnd] * enh_fct;
-        ss_aer[1] = tab[SN_BC2 + 0 + idx_ncl * 5 + bnd];
-        asm_aer[1] = tab[SN_BC2 + 50 + idx_ncl * 5 + bnd];
-        ext_aer[1] = tab[SN_BC2 + 100 + idx_ncl * 5 + bnd];
-
-        const double L_snw = ice[i] + liq[i];
-        const double tau_snw = L_snw * ext_snw;
-        double tau_sum = 0.0, omega_sum = 0.0, g_sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const double L_aer = L_snw * mss[i][j];
-          const double tau_aer = L_aer * ext_aer[j];
-          tau_sum += tau_aer;
-          omega_sum += (tau_aer * ss_aer[j]);
-          g_sum += (tau_aer * ss_aer[j] * asm_aer[j]);
-        }
-        const double tau = tau_sum + tau_snw;
-        const double omega = (1.0 / tau) * (omega_sum + (ss_snw * tau_snw));
-        const double g = (1.0 / (tau * omega)) * (g_sum + (asm_snw * ss_snw * tau_snw));
-        g_star[i] = g / (1.0 + g);
-        omega_star[i] = ((1.0 - pow(g, 2.0)) * omega) / (1.0 - (omega * pow(g, 2.0)));
-        tau_star[i] = (1.0 - (omega * pow(g, 2.0))) * tau;
-      }
-    }
-
-    // ---- snow_radiative_transfer_solver for this band (:384-667)
-    double trndir[6], trntdr[6], trndif[6], rdndif[6];
-    double rdir[5], rdif_a[5], tdir[5], tdif_a[5], trnlay[5];  // rdif_b == rdif_a, tdif_b == tdif_a (:489-490)
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      trndir[i] = c0;
-      trntdr[i] = c0;
-      trndif[i] = c0;
+  for (int i = 0; i < 5; i++) {
+    if (i == snl_top) {
+      trndir[i] = c1;
+      trntdr[i] = c1;
+      trndif[i] = c1;
       rdndif[i] = c0;
     }
+    rdir[i] = c0;
+    rdif_a[i] = c0;
+    tdir[i] = c0;
+    tdif_a[i] = c0;
+    trnlay[i] = c0;
+    if (i >= snl_top) {
+      if (trntdr[i] > trmin) {
+        const double ts = tau_star[i];
+        const double ws = omega_star[i];
+        const double gs = g_star[i];
+        const double lm = sqrt(c3 * (c1 - ws) * (c1 - ws * gs));
+        const double ue = c1p5 * (c1 - ws * gs) / lm;
+        const double extins = dmax(SN_EXP_MIN, exp(-lm * ts));
+        const double ne = ((ue + c1) * (ue + c1) / extins) - ((ue - c1) * (ue - c1) * extins);
+        const double R1 = (pow(ue, 2.0) - c1) * (c1 / extins - extins) / ne;
+        const double T1 = c4 * ue / ne;
+        trnlay[i] = dmax(SN_EXP_MIN, exp(-ts / mu_not));
+        double alp = cp75 * ws * mu_not * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu_not * mu_not));
+        double gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu_not * mu_not) / (c1 - lm * lm * mu_not * mu_not));
+        double apg = alp + gam;
+        double amg = alp - gam;
+        rdir[i] = apg * R1 + amg * (T1 * trnlay[i] - c1);
+        tdir[i] = apg * T1 + (amg * R1 - apg + c1) * trnlay[i];
+        double swt = c0, smr = c0, smt = c0;
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
+        for (int ng = 0; ng < 8; ++ng) {
+          const double mu = difgauspt[ng];
+          const double gwt = difgauswt[ng];
+          swt = swt + mu * gwt;
+          const double trn = dmax(SN_EXP_MIN, exp(-ts / mu));
+          alp = cp75 * ws * mu * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu * mu));
+          gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu * mu) / (c1 - lm * lm * mu * mu));
+          apg = alp + gam;
+          amg = alp - gam;
+          const double rdr = apg * R1 + amg * T1 * trn - amg;
+          const double tdr = apg * T1 + amg * R1 * trn - apg * trn + trn;
+          smr = smr + mu * rdr * gwt;
+          smt = smt + mu * tdr * gwt;
+        }
+        rdif_a[i] = smr / swt;
+        tdif_a[i] = smt / swt;
+      }
+      trndir[i + 1] = trndir[i] * trnlay[i];
+      const double refkm1 = c1 / (c1 - rdndif[i] * rdif_a[i]);
+      const double tdrrdir = trndir[i] * rdir[i];
+      const double tdndif = trntdr[i] - trndir[i];
+      trntdr[i + 1] = trndir[i] * tdir[i] + (tdndif + tdrrdir * rdndif[i]) * refkm1 * tdif_a[i];
+      rdndif[i + 1] = rdif_a[i] + (tdif_a[i] * rdndif[i] * refkm1 * tdif_a[i]);
+      trndif[i + 1] = trndif[i] * refkm1 * tdif_a[i];
+    }
+  }
+
+  // upward sweep from the ground interface (:506-524)
+  double rupdir[6], rupdif[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    rupdir[i] = c0;
+    rupdif[i] = c0;
+  }
+  rupdir[5] = albsoi_b;  // albsoi(VIS) for band 0, albsoi(NIR) for the other bands
+  rupdif[5] = albsoi_b;
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    if (i >= snl_top) {
+      const double refkp1 = c1 / (c1 - rdif_a[i] * rupdif[i + 1]);
+      rupdir[i] = rdir[i] + (trnlay[i] * rupdir[i + 1] + (tdir[i] - trnlay[i]) * rupdif[i + 1]) * refkp1 * tdif_a[i];
+      rupdif[i] = rdif_a[i] + tdif_a[i] * rupdif[i + 1] * refkp1 * tdif_a[i];
+    }
+  }
+
+  // net interface fluxes (:540-569); dftmp = dfdir (direct pass) or dfdif (diffuse pass) (:571-591)
+  double dftmp[6];
+  double F_sfc_pls = 0.0;
+  albedo = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    dftmp[i] = c0;
+    if (i >= snl_top) {
+      const double refk = c1 / (c1 - rdndif[i] * rupdif[i]);
+      if (pass == 0) {
+        double dfdir = trndir[i] + (trntdr[i] - trndir[i]) * (c1 - rupdif[i]) * refk -
+                       trndir[i] * rupdir[i] * (c1 - rdndif[i]) * refk;
+        if (dfdir < puny) dfdir = c0;
+        dftmp[i] = dfdir;
+      } else {
+        double dfdif = trndif[i] * (c1 - rupdif[i]) * refk;
+        if (dfdif < puny) dfdif = c0;
+        dftmp[i] = dfdif;
+      }
       if (i == snl_top) {
-        trndir[i] = c1;
-        trntdr[i] = c1;
-        trndif[i] = c1;
-        rdndif[i] = c0;
-      }
-      rdir[i] = c0;
-      rdif_a[i] = c0;
-      tdir[i] = c0;
-      tdif_a[i] = c0;
-      trnlay[i] = c0;
-      if (i >= snl_top) {
-        if (trntdr[i] > trmin) {
-          const double ts = tau_star[i];
-          const double ws = omega_star[i];
-          const double gs = g_star[i];
-          const double lm = sqrt(c3 * (c1 - ws) * (c1 - ws * gs));
-          const double ue = c1p5 * (c1 - ws * gs) / lm;
-          const double extins = dmax(SN_EXP_MIN, exp(-lm * ts));
-          const double ne = ((ue + c1) * (ue + c1) / extins) - ((ue - c1) * (ue - c1) * extins);
-          const double R1 = (pow(ue, 2.0) - c1) * (c1 / extins - extins) / ne;
-          const double T1 = c4 * ue / ne;
-          trnlay[i] = dmax(SN_EXP_MIN, exp(-ts / mu_not));
-          double alp = cp75 * ws * mu_not * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu_not * mu_not));
-          double gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu_not * mu_not) / (c1 - lm * lm * mu_not * mu_not));
-          double apg = alp + gam;
-          double amg = alp - gam;
-          rdir[i] = apg * R1 + amg * (T1 * trnlay[i] - c1);
-          tdir[i] = apg * T1 + (amg * R1 - apg + c1) * trnlay[i];
-          double swt = c0, smr = c0, smt = c0;
-#pragma unroll
-          for (int ng = 0; ng < 8; ++ng) {
-            const double mu = difgauspt[ng];
-            const double gwt = difgauswt[ng];
-            swt = swt + mu * gwt;
-            const double trn = dmax(SN_EXP_MIN, exp(-ts / mu));
-            alp = cp75 * ws * mu * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu * mu));
-            gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu * mu) / (c1 - lm * lm * mu * mu));
-            apg = alp + gam;
-            amg = alp - gam;
-            const double rdr = apg * R1 + amg * T1 * trn - amg;
-            const double tdr = apg * T1 + amg * R1 * trn - apg * trn + trn;
-            smr = smr + mu * rdr * gwt;
-            smt = smt + mu * tdr * gwt;
-          }
-          rdif_a[i] = smr / swt;
-          tdif_a[i] = smt / swt;
-        }
-        trndir[i + 1] = trndir[i] * trnlay[i];
-        const double refkm1 = c1 / (c1 - rdndif[i] * rdif_a[i]);
-        const double tdrrdir = trndir[i] * rdir[i];
-        const double tdndif = trntdr[i] - trndir[i];
-        trntdr[i + 1] = trndir[i] * tdir[i] + (tdndif + tdrrdir * rdndif[i]) * refkm1 * tdif_a[i];
-        rdndif[i + 1] = rdif_a[i] + (tdif_a[i] * rdndif[i] * refkm1 * tdif_a[i]);
-        trndif[i + 1] = trndif[i] * refkm1 * tdif_a[i];
-      }
-    }
-
-    // upward sweep from the ground interface (:506-524)
-    double rupdir[6], rupdif[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      rupdir[i] = c0;
-      rupdif[i] = c0;
-    }
-    rupdir[5] = albsoi[1];
-    rupdif[5] = albsoi[1];
-    if (bnd == 0) {
-      rupdir[5] = albsoi[0];
-      rupdif[5] = albsoi[0];
-    }
-#pragma unroll
-    for (int i = 4; i >= 0; --i) {
-      if (i >= snl_top) {
-        const double refkp1 = c1 / (c1 - rdif_a[i] * rupdif[i + 1]);
-        rupdir[i] = rdir[i] + (trnlay[i] * rupdir[i + 1] + (tdir[i] - trnlay[i]) * rupdif[i + 1]) * refkp1 * tdif_a[i];
-        rupdif[i] = rdif_a[i] + tdif_a[i] * rupdif[i + 1] * refkp1 * tdif_a[i];
-      }
-    }
-
-    // net interface fluxes (:540-569); dftmp = dfdir (direct pass) or dfdif (diffuse pass) (:571-591)
-    double dftmp[6];
-    double albedo = 0.0, F_sfc_pls = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      dftmp[i] = c0;
-      if (i >= snl_top) {
-        const double refk = c1 / (c1 - rdndif[i] * rupdif[i]);
-        if (FLG == 1) {
-          double dfdir = trndir[i] + (trntdr[i] - trndir[i]) * (c1 - rupdif[i]) * refk -
-                         trndir[i] * rupdir[i] * (c1 - rdndif[i]) * refk;
-          if (dfdir < puny) dfdir = c0;
-          dftmp[i] = dfdir;
+        if (pass == 0) {
+          albedo = rupdir[i];
+          F_sfc_pls = (trndir[i] * rupdir[i] + (trntdr[i] - trndir[i]) * rupdif[i]) * refk;
         } else {
-          double dfdif = trndif[i] * (c1 - rupdif[i]) * refk;
-          if (dfdif < puny) dfdif = c0;
-          dftmp[i] = dfdif;
-        }
-        if (i == snl_top) {
-          if (FLG == 1) {
-            albedo = rupdir[i];
-            F_sfc_pls = (trndir[i] * rupdir[i] + (trntdr[i] - trndir[i]) * rupdif[i]) * refk;
-          } else {
-            albedo = rupdif[i];
-            F_sfc_pls = trndif[i] * rupdif[i] * refk;
-          }
+          albedo = rupdif[i];
+          F_sfc_pls = trndif[i] * rupdif[i] * refk;
         }
       }
     }
+  }
 
-    // absorbed flux per layer + ground (:594-650)
-    double F_abs_sum = 0.0;
-    double fl[6];
+  // absorbed flux per layer + ground (:594-650)
+  double F_abs_sum = 0.0;
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      fl[i] = 0.0;
-      if (i >= snl_top) {
-        const double F_abs = dftmp[i] - dftmp[i + 1];
-        fl[i] = F_abs;
-        if (F_abs < -0.00001) err |= ELMK_ERR_SNICAR_NEG_ABS;
-        F_abs_sum = F_abs_sum + F_abs;
-      }
+  for (int i = 0; i < 5; i++) {
+    fl[i] = 0.0;
+    if (i >= snl_top) {
+      const double F_abs = dftmp[i] - dftmp[i + 1];
+      fl[i] = F_abs;
+      if (F_abs < -0.00001) err |= ELMK_ERR_SNICAR_NEG_ABS;
+      F_abs_sum = F_abs_sum + F_abs;
     }
-    const double F_btm_net = dftmp[5];
-    fl[5] = F_btm_net;
+  }
+  const double F_btm_net = dftmp[5];
+  fl[5] = F_btm_net;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (i >= snl_top && fl[i] < 0.0) fl[i] = 0.0;  // underflow clamp (:640-644)
+  }
+  const double energy_sum = (mu_not * ELM_PI * flx_slrd) + flx_slri - (F_abs_sum + F_btm_net + F_sfc_pls);
+  if (fabs(energy_sum) > 0.00001) err |= ELMK_ERR_SNICAR_ENERGY;
+  if (albedo > 1.0) err |= ELMK_ERR_SNICAR_ALBEDO;
+}
+
+// snow_albedo_radiation_factor (:673-757) for one pass of one column, from the five band results held by five
+// consecutive lanes (band b at lane g0 + b): VIS is band 0, NIR the flux-weighted sum of bands 1..4 in band order.
+// Every lane of the group computes the same values; the caller lets one of them store.
+template <int NL>
+__device__ __forceinline__ void snicar_combine(const int g0, const int pass, const double mu_not, const int rds_top,
+                                               const double albedo, const double (&fl)[6], SnowOut& out)
+{
+  constexpr int snl_top = 5 - NL;
+  // 5-band flux weights (:710-723)
+  const double w1 = (pass == 0) ? 0.49352158521175 : 0.58581507618433;
+  const double w2 = (pass == 0) ? 0.18099494230665 : 0.20156903770812;
+  const double w3 = (pass == 0) ? 0.12094898498813 : 0.10917889346386;
+  const double w4 = (pass == 0) ? 0.20453448749347 : 0.10343699264369;
+  const double flx_wgt[5] = {1.0, w1, w2, w3, w4};
+  double alb_nir_sum = 0.0, wgt_sum = 0.0;
+  double nir_sum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  out.alb[0] = __shfl(albedo, g0, 64);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    out.fabs_[i][0] = __shfl(fl[i], g0, 64);  // zero wherever the solver does not write (i < snl_top)
+    out.fabs_[i][1] = 0.0;
+  }
+#pragma unroll
+  for (int b = 1; b < 5; b++) {
+    alb_nir_sum += flx_wgt[b] * __shfl(albedo, g0 + b, 64);
+    wgt_sum += flx_wgt[b];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      if (i >= snl_top && fl[i] < 0.0) fl[i] = 0.0;  // underflow clamp (:640-644)
-    }
-    const double energy_sum = (mu_not * ELM_PI * flx_slrd) + flx_slri - (F_abs_sum + F_btm_net + F_sfc_pls);
-    if (fabs(energy_sum) > 0.00001) err |= ELMK_ERR_SNICAR_ENERGY;
-    if (albedo > 1.0) err |= ELMK_ERR_SNICAR_ALBEDO;
-
-    // ---- snow_albedo_radiation_factor, folded in band by band (:724-741)
-    if (bnd == 0) {
-      out.alb[0] = albedo;
-#pragma unroll
-      for (int i = 0; i < 6; i++) out.fabs_[i][0] = fl[i];
-    } else {
-      alb_nir_sum += flx_wgt[bnd] * albedo;
-      wgt_sum += flx_wgt[bnd];
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        if (i >= snl_top) nir_sum[i] += flx_wgt[bnd] * fl[i];
-      }
+      const double f = __shfl(fl[i], g0 + b, 64);
+      if (i >= snl_top) nir_sum[i] += flx_wgt[b] * f;
     }
   }
   out.alb[1] = alb_nir_sum / wgt_sum;
@@ -310,19 +333,13 @@ __device__ __forceinline__ void snicar_pass(const double* __restrict__ tab, doub
     if (i >= snl_top) out.fabs_[i][1] = nir_sum[i] / wgt_sum;
   }
   // near-IR direct albedo/absorption adjustment at high solar zenith angle (:748-757)
-  if (FLG == 1 && mu_not < 0.2588) {
+  if (pass == 0 && mu_not < 0.2588) {
     const double sza_c1 = 0.085730 + (-0.630883) * mu_not + 1.303723 * pow(mu_not, 2.0);
     const double sza_c0 = 1.467291 + (-3.338043) * mu_not + 6.807489 * pow(mu_not, 2.0);
-    int rtop = rds[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (i == snl_top) rtop = rds[i];
-    const double sza_factor = sza_c1 * (log10(rtop * 1.0) - 6.0) + sza_c0;
+    const double sza_factor = sza_c1 * (log10(rds_top * 1.0) - 6.0) + sza_c0;
     const double flx_sza_adjust = out.alb[1] * (sza_factor - 1.0) * wgt_sum;
     out.alb[1] *= sza_factor;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-      if (i == snl_top) out.fabs_[i][1] -= flx_sza_adjust;
+    out.fabs_[snl_top][1] -= flx_sza_adjust;
   }
 }
 
@@ -342,52 +359,7 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
   S->tlai_z[c] = elai;
   // (laisum/saisum of a single layer equal elai/esai exactly: the reference's consistency throw cannot fire)
 
-  // ---- init_timestep (:90-151): night / default values
-  double vcmaxcintsun = 0.0;
-  double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
-  if (elai > 0.0) {
-    vcmaxcintsha /= elai;
-  } else {
-    vcmaxcintsha = 0.0;
-  }
-
-  if (!(coszen > 0.0)) {
-    // nothing after init_timestep runs at night except snow_albedo_radiation_factor's "no sun" branch (:758-765)
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++) {
-      LV(albsod, ib) = 0.0;
-      LV(albsoi, ib) = 0.0;
-      LV(albgrd, ib) = 0.0;
-      LV(albgri, ib) = 0.0;
-      LV(albd, ib) = 1.0;
-      LV(albi, ib) = 1.0;
-      LV(fabd, ib) = 0.0;
-      LV(fabi, ib) = 0.0;
-      LV(fabi_sun, ib) = 0.0;
-      LV(fabi_sha, ib) = 0.0;
-      LV(ftdd, ib) = 0.0;
-      LV(ftid, ib) = 0.0;
-      LV(ftii, ib) = 0.0;
-      LV(albsnd, ib) = 0.0;
-      LV(albsni, ib) = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      LV(flx_absdv, i) = 0.0;
-      LV(flx_absdn, i) = 0.0;
-      LV(flx_absiv, i) = 0.0;
-      LV(flx_absin, i) = 0.0;
-    }
-    S->vcmaxcintsun[c] = vcmaxcintsun;
-    S->vcmaxcintsha[c] = vcmaxcintsha;
-    S->fsun_z[c] = 0.0;
-    S->fabd_sun_z[c] = 0.0;
-    S->fabd_sha_z[c] = 0.0;
-    S->fabi_sun_z[c] = 0.0;
-    S->fabi_sha_z[c] = 0.0;
-    return -1;  // night column: complete
-  }
-
+  if (!(coszen > 0.0)) return -1;  // night column: stage 3 writes the init_timestep defaults
 
   // =========================== sunlit column ===========================
   const double h2osno = S->h2osno[c];
@@ -436,8 +408,6 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
   LV(albsod, 1) = albsod[1];
   LV(albsoi, 0) = albsoi[0];
   LV(albsoi, 1) = albsoi[1];
-  (void)vcmaxcintsun;
-  (void)vcmaxcintsha;
   if (h2osno > SN_MIN_SNW) return snl == 0 ? 1 : snl;  // snl == 0: one fictitious fresh-snow layer (flg_nosnl, :42-48)
   return 0;
 }
@@ -646,109 +616,156 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
 }
 
 // =====================================================================================================
-// stage 1: every column
+// stage 1 (coalesced, every column): canopy_layer_lai, soil albedo of the sunlit columns, and the classification of
+// the sunlit snow-covered columns by their number of snow layers (lists LIST_ALB_1..5)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_alb_main(const DevState* __restrict__ S)
+__global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict__ S)
 {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   const Land L = S->land;
   if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
   const bool inside = c < S->ncols;
-  int nl = -1;  // >= 0: sunlit column, goes to stage 2 with nl snow layers (0: snow-free)
+  int nl = -1;  // >= 1: sunlit column with snow, goes through SNICAR with nl layers
   if (inside) nl = alb_main_column(S, c, ld, L);
-  block_classify_append<6>(S->lists, ld, S->counters, LIST_ALB_0, nl, (int32_t)c);
+  block_classify_append<5>(S->lists, ld, S->counters, LIST_ALB_1, nl >= 1 ? nl - 1 : -1, (int32_t)c);
 }
 
 // =====================================================================================================
-// stage 2: sunlit snow-covered columns with exactly NL (possibly fictitious) snow layers
+// stage 2: SNICAR for the sunlit snow-covered columns with exactly NL (possibly fictitious) snow layers.
+// Ten lanes per column - (direct, diffuse) x 5 bands - six columns per wave; lanes 60..63 idle.
+// The two SnowOut (one per pass) go to the scratch array alb_snow, by column.
 // =====================================================================================================
+// (alb_snow holds 28 doubles per column: pass x {alb[2], fabs_[6][2]})
 template <int NL>
-__global__ __launch_bounds__(256) void k_alb_snow(const DevState* __restrict__ S)
+__global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restrict__ S)
 {
   const int64_t ld = S->ld;
-  const Land L = S->land;
   const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
   const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
   constexpr int snl_top = NLEVSNO - NL;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
-    const int64_t c = list[q];
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 10, task = lane - slot * 10;  // slot 6 (lanes 60..63): no column
+  const int pass = task / 5, bnd = task - pass * 5;
+  const int g0 = lane - bnd;  // first lane of this (column, pass) group
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); (uint64_t)w * 6u < count; w += nwaves) {
+    const uint32_t q = w * 6u + (uint32_t)slot;
+    const bool valid = slot < 6 && q < count;
+    const int64_t c = list[valid ? q : w * 6u];  // lanes without a column shadow the wave's first one and store nothing
     uint32_t err = 0;
-    const double coszen = S->coszen[c];
-    const double elai = S->elai[c], esai = S->esai[c];
-    const double h2osno = S->h2osno[c];
+    const double mu_not = dmax(S->coszen[c], 0.01);
     const int snl = S->snl[c];
-    const double albsod[2] = {LV(albsod, 0), LV(albsod, 1)};
-    const double albsoi[2] = {LV(albsoi, 0), LV(albsoi, 1)};
-    // init_timestep values of the leaf-to-canopy scaling coefficients (overwritten by two_stream where vegetated)
-    double vcmaxcintsun = 0.0;
-    double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
-    if (elai > 0.0) {
-      vcmaxcintsha /= elai;
-    } else {
-      vcmaxcintsha = 0.0;
-    }
-
-    SnowOut sd, si;
-    if constexpr (NL == 0) {
-      // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
+    const double h2osno = S->h2osno[c];
+    const double albsoi_b = LV(albsoi, bnd == 0 ? 0 : 1);
+    double albedo, fl[6];
+    snicar_band<NL>(S, c, ld, pass, bnd, mu_not, snl, h2osno, albsoi_b, albedo, fl, err);
+    int rds_top = (snl == 0) ? (int)round(SNW_RDS_MIN) : (int)round(LV(snw_rds, snl_top));
+    rds_top = rds_top < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : (rds_top > SN_RDS_MAX_TBL ? SN_RDS_MAX_TBL : rds_top);
+    SnowOut out;
+    snicar_combine<NL>(g0, pass, mu_not, rds_top, albedo, fl, out);
+    if (valid && bnd == 0) {
+      double* __restrict__ o = S->alb_snow + (int64_t)(pass * 14) * ld + c;
+      o[0] = out.alb[0];
+      o[ld] = out.alb[1];
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
-        si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
-      }
-      if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
-        sd.alb[0] = si.alb[0] = albsoi[0];
-        sd.alb[1] = si.alb[1] = albsoi[1];
-      } else {
-        sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
-      }
-      (void)snl;
-    } else {
-    int rds[5] = {0, 0, 0, 0, 0};
-    double ice[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, liq[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (snl == 0) {  // only possible for NL == 1
-      ice[4] = h2osno;
-      liq[4] = 0.0;
-      rds[4] = (int)round(SNW_RDS_MIN);
-    } else {
-#pragma unroll
-      for (int i = snl_top; i < 5; i++) {  // the reference copies all five levels; only i >= snl_top is ever read
-        liq[i] = LV(h2osoi_liq, i);
-        ice[i] = LV(h2osoi_ice, i);
-        rds[i] = (int)round(LV(snw_rds, i));
+        o[(int64_t)(2 + 2 * i) * ld] = out.fabs_[i][0];
+        o[(int64_t)(3 + 2 * i) * ld] = out.fabs_[i][1];
       }
     }
-#pragma unroll
-    for (int i = snl_top; i < 5; i++) {
-      if (rds[i] < SN_RDS_MIN_TBL || rds[i] > SN_RDS_MAX_TBL) {
-        err |= ELMK_ERR_SNICAR_RDS;  // the reference throws (:74-78); clamp so the table gather stays in range
-        rds[i] = rds[i] < SN_RDS_MIN_TBL ? SN_RDS_MIN_TBL : SN_RDS_MAX_TBL;
-      }
-    }
-    const double mu_not = dmax(coszen, 0.01);
-    // aerosol concentrations (surface_albedo_impl.hh:141-150): OC species 2,3 are ignored
-    double mss[5][8];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) mss[i][j] = 0.0;
-    }
-#pragma unroll
-    for (int i = snl_top; i < 5; i++) {
-      mss[i][0] = LV(cnc_bcphi, i);
-      mss[i][1] = LV(cnc_bcpho, i);
-      mss[i][4] = LV(cnc_dst1, i);
-      mss[i][5] = LV(cnc_dst2, i);
-      mss[i][6] = LV(cnc_dst3, i);
-      mss[i][7] = LV(cnc_dst4, i);
-    }
-    snicar_pass<1, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, sd, err);
-    snicar_pass<2, NL>(S->snicar, mu_not, rds, ice, liq, mss, albsoi, si, err);
-    }
-    alb_finish(S, c, ld, L, coszen, elai, esai, S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
-    if (err) S->err_flags[c] |= err;
+    if (valid && err) atomicOr(&S->err_flags[c], err);
   }
+}
+
+// =====================================================================================================
+// stage 3 (coalesced, every column): night defaults (init_timestep), or for a sunlit column ground_albedo,
+// flux_absorption_factor and the canopy two-stream solution from the soil albedos and the SNICAR products
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ S)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  if (L.urbpoi || c >= S->ncols) return;
+  const double coszen = S->coszen[c];
+  const double elai = S->elai[c];
+  // init_timestep values of the leaf-to-canopy scaling coefficients (overwritten by two_stream where vegetated)
+  double vcmaxcintsun = 0.0;
+  double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
+  if (elai > 0.0) {
+    vcmaxcintsha /= elai;
+  } else {
+    vcmaxcintsha = 0.0;
+  }
+  if (!(coszen > 0.0)) {
+    // nothing after init_timestep runs at night except snow_albedo_radiation_factor's "no sun" branch (:758-765)
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {
+      LV(albsod, ib) = 0.0;
+      LV(albsoi, ib) = 0.0;
+      LV(albgrd, ib) = 0.0;
+      LV(albgri, ib) = 0.0;
+      LV(albd, ib) = 1.0;
+      LV(albi, ib) = 1.0;
+      LV(fabd, ib) = 0.0;
+      LV(fabi, ib) = 0.0;
+      LV(fabi_sun, ib) = 0.0;
+      LV(fabi_sha, ib) = 0.0;
+      LV(ftdd, ib) = 0.0;
+      LV(ftid, ib) = 0.0;
+      LV(ftii, ib) = 0.0;
+      LV(albsnd, ib) = 0.0;
+      LV(albsni, ib) = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      LV(flx_absdv, i) = 0.0;
+      LV(flx_absdn, i) = 0.0;
+      LV(flx_absiv, i) = 0.0;
+      LV(flx_absin, i) = 0.0;
+    }
+    S->vcmaxcintsun[c] = vcmaxcintsun;
+    S->vcmaxcintsha[c] = vcmaxcintsha;
+    S->fsun_z[c] = 0.0;
+    S->fabd_sun_z[c] = 0.0;
+    S->fabd_sha_z[c] = 0.0;
+    S->fabi_sun_z[c] = 0.0;
+    S->fabi_sha_z[c] = 0.0;
+    return;
+  }
+  const double h2osno = S->h2osno[c];
+  const double albsod[2] = {LV(albsod, 0), LV(albsod, 1)};  // written by stage 1
+  const double albsoi[2] = {LV(albsoi, 0), LV(albsoi, 1)};
+  SnowOut sd, si;
+  if (h2osno > SN_MIN_SNW) {
+    const double* __restrict__ o = S->alb_snow + c;
+    sd.alb[0] = o[0];
+    sd.alb[1] = o[ld];
+    si.alb[0] = o[(int64_t)14 * ld];
+    si.alb[1] = o[(int64_t)15 * ld];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      sd.fabs_[i][0] = o[(int64_t)(2 + 2 * i) * ld];
+      sd.fabs_[i][1] = o[(int64_t)(3 + 2 * i) * ld];
+      si.fabs_[i][0] = o[(int64_t)(16 + 2 * i) * ld];
+      si.fabs_[i][1] = o[(int64_t)(17 + 2 * i) * ld];
+    }
+  } else {
+    // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
+      si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
+    }
+    if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
+      sd.alb[0] = si.alb[0] = albsoi[0];
+      sd.alb[1] = si.alb[1] = albsoi[1];
+    } else {
+      sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
+    }
+  }
+  alb_finish(S, c, ld, L, coszen, elai, S->esai[c], S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
 }
 
 __global__ void k_alb_reset(const DevState* __restrict__ S)
@@ -764,24 +781,26 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   if (n <= 0) return;
   const dim3 block(256);
   const unsigned full = (unsigned)((n + 255) / 256);
-  const unsigned capped = full < 2048u ? full : 2048u;  // queue kernels are grid-stride over a device-side count
+  // stage 2 is grid-stride over a device-side count: 24 columns per workgroup
+  const unsigned want = (unsigned)((n + 23) / 24);
+  const unsigned capped = want < 4096u ? want : 4096u;
   hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
-  hipLaunchKernelGGL(k_alb_main, dim3(full), block, 0, st, S);
-  // The six layer-count queues are independent, each is a latency-bound launch of about one wave per SIMD
-  // (the unrolled SNICAR state of NL layers takes 250-450 VGPRs), and each alone leaves the last round of waves
-  // mostly empty.  They run beside each other on side streams, so idle CUs of one fill with workgroups of another.
+  hipLaunchKernelGGL(k_alb_classify, dim3(full), block, 0, st, S);
+  // The five layer-count queues are independent: side streams let their launches overlap (fork/join with events).
+  // (One persistent launch draining all five lists through a chunk counter was measured 30 % slower: every wave then
+  // pays the deepest list's register footprint, and the five unrolled bodies compete for the instruction cache.)
   (void)hipEventRecord(side->fork, st);
-  for (int i = 0; i < ELMK_NSIDE; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
-  hipLaunchKernelGGL(k_alb_snow<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
-  hipLaunchKernelGGL(k_alb_snow<4>, dim3(capped), block, 0, side->s[0], S);
-  hipLaunchKernelGGL(k_alb_snow<3>, dim3(capped), block, 0, side->s[1], S);
-  hipLaunchKernelGGL(k_alb_snow<2>, dim3(capped), block, 0, side->s[2], S);
-  hipLaunchKernelGGL(k_alb_snow<1>, dim3(capped), block, 0, side->s[3], S);
-  hipLaunchKernelGGL(k_alb_snow<0>, dim3(capped), block, 0, side->s[4], S);
-  for (int i = 0; i < ELMK_NSIDE; i++) {
+  for (int i = 0; i < 4; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
+  hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
+  hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, side->s[0], S);
+  hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, side->s[1], S);
+  hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, side->s[2], S);
+  hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, side->s[3], S);
+  for (int i = 0; i < 4; i++) {
     (void)hipEventRecord(side->join[i], side->s[i]);
     (void)hipStreamWaitEvent(st, side->join[i], 0);
   }
+  hipLaunchKernelGGL(k_alb_final, dim3(full), block, 0, st, S);
 }
 
 }  // namespace elmk

@@ -15,4 +15,4 @@ for _ in range(2):
     D.restore_fields()
     st.timestep7(D, 1800.0)
 D.sync()
-np.savez(sys.argv[1], trips=D.canopy_trip_counts(), **{k: D.download(k) for k in ("t_veg", "cgrnd", "eflx_sh_veg", "h2ocan", "t_ref2m", "nrad")})
+np.savez(sys.argv[1], trips=D.canopy_trip_counts(), **{k: D.download(k) for k in ("t_veg", "cgrnd", "eflx_sh_veg", "h2ocan", "t_ref2m", "nrad", "albd", "albi", "fabd", "fabi", "ftid", "ftii", "ftdd", "flx_absdv", "flx_absdn", "flx_absiv", "flx_absin", "albsnd", "albsni", "albgrd", "albgri", "albsod", "vcmaxcintsun", "vcmaxcintsha", "fabd_sun_z", "fabi_sha_z", "fsun_z", "err_flags", "sabg_lyr", "sabv")})

@@ -13,6 +13,7 @@ from .state import (  # noqa: F401
     kokkos_albedo_snicar,
     kokkos_bareground_fluxes,
     kokkos_canopy_fluxes,
+    kokkos_soil_temperature,
     kokkos_canopy_hydrology,
     kokkos_canopy_temperature,
     kokkos_frac_wet,

@@ -560,6 +560,14 @@ int elmk_canopy_fluxes(elmk_ctx* ctx, double dt)
   return ELMK_OK;
 }
 
+int elmk_soil_temperature(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
 // ELMInterface::advance order (elm_kokkos_interface.cc:289-307)
 int elmk_timestep7(elmk_ctx* ctx, double dt)
 {

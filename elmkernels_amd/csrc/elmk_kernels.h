@@ -27,6 +27,8 @@ void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);
 void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+// next row after the seven: soil / snow column temperature
+void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st);
 
 // layout conversion between the reference's [column][level] host layout and device SoA [level][column]
 // staging: dense buffer of n*nlev elements in device memory; elem = element size in bytes (1, 4 or 8)

@@ -251,6 +251,11 @@ def kokkos_canopy_fluxes(S, dt):
     S._chk(S.lib.elmk_canopy_fluxes(S.ctx, float(dt)), "canopy_fluxes")
 
 
+def kokkos_soil_temperature(S, dt):
+    """Next in ELMInterface::advance after the seven (elm_kokkos_interface.cc:310; soil_temperature_kokkos.cc:6-278)."""
+    S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")
+
+
 def timestep7(S, dt):
     """The seven calls of ELMInterface::advance (driver/kokkos/elm_kokkos_interface.cc:289-307), in order."""
     S._chk(S.lib.elmk_timestep7(S.ctx, float(dt)), "timestep7")

@@ -90,6 +90,14 @@ def base_columns(field_table):
         out[f"forc_hgt_{k}_patch"][:] = extras["forc_hgt_" + k][:, 0]
     out["watdry"][:] = 0.0
     out["watopt"][:] = 0.0
+    # soil thermal parameters (soil_texture_hydraulic_model in the reference driver; no fixture carries them):
+    # mineral conductivity, dry conductivity, solid heat capacity - plausible loam values varied over level and column
+    if "tkmg" in out:
+        k = (np.arange(n)[:, None] * 7 % 11 - 5) / 50.0
+        j = np.arange(15)[None, :]
+        out["tkmg"][:] = (2.0 + 0.08 * j) * (1.0 + k)
+        out["tkdry"][:] = (0.20 + 0.005 * j) * (1.0 - k)
+        out["csol"][:, 5:] = (2.0e6 + 2.0e4 * j) * (1.0 + 0.5 * k)
     scal = dict(
         dewmx=float(extras["dewmx"][0, 0]), oldfflag=int(extras["oldfflag"][0, 0]),
         dayl=float(extras["dayl"][n // 2, 0]), max_dayl=float(extras["max_dayl"][n // 2, 0]),

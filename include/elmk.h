@@ -26,6 +26,7 @@
  *   kokkos_bareground_fluxes(S)     bareground_fluxes_kokkos.hh       elmk_bareground_fluxes
  *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
  *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7
+ *   kokkos_soil_temperature(S,dt)   soil_temperature_kokkos.hh        elmk_soil_temperature
  *   throw / assert inside physics   (list: SURVEY.md section 5)       per-column flag word, elmk_error_summary
  *
  * Conventions
@@ -181,6 +182,10 @@ int elmk_canopy_temperature(elmk_ctx *ctx);
 int elmk_bareground_fluxes(elmk_ctx *ctx);
 int elmk_canopy_fluxes(elmk_ctx *ctx, double dt);
 int elmk_timestep7(elmk_ctx *ctx, double dt);
+/* next in ELMInterface::advance (elm_kokkos_interface.cc:310): kokkos_soil_temperature(S, dt),
+ * soil_temperature_kokkos.cc:6-278 - thermal properties, the 21-row pentadiagonal temperature system of
+ * snow / standing surface water / soil, its solve, phase change, ground temperature */
+int elmk_soil_temperature(elmk_ctx *ctx, double dt);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* OR of all columns' flag words and the first column with a fatal bit (-1 if none); synchronises */

@@ -140,7 +140,11 @@ typedef struct {
   X(dz, D, 20) X(zsoi, D, 20) X(zisoi, D, 21)                                                               \
   X(vtype, I, 1) X(veg_active, B, 1) X(do_capsnow, I, 1)                                                    \
   X(cnc_bcphi, D, 5) X(cnc_bcpho, D, 5) X(cnc_dst1, D, 5) X(cnc_dst2, D, 5) X(cnc_dst3, D, 5)                \
-  X(cnc_dst4, D, 5)
+  X(cnc_dst4, D, 5)                                                                                         \
+  /* soil_temperature (next row after the seven wrappers): elm_state.h:86,139-155 */                        \
+  X(tkmg, D, 15) X(tkdry, D, 15) X(csol, D, 20) X(fact, D, 20) X(imelt, I, 20) X(xmf, D, 1)                  \
+  X(xmf_h2osfc, D, 1) X(qflx_h2osfc_ice, D, 1) X(eflx_h2osfc_snow, D, 1) X(qflx_snofrz, D, 1)                \
+  X(qflx_snomelt, D, 1) X(eflx_snomelt, D, 1) X(qflx_snofrz_lyr, D, 5) X(sabg_chk, D, 1)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -198,6 +202,16 @@ void elmo_canopy_fluxes_given(elmo_state *S, double dt, const double *rho_in, co
                               const double *pco2_in, int *niter);
 void elmo_bareground_fluxes_given(elmo_state *S, const double *rho_in);
 void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha_out);
+/* next row: soil_temperature_kokkos.cc:6-278 (follows the seven wrappers in ELMInterface::advance, :310) */
+void elmo_soil_temperature(elmo_state *S, double dt);
+/* the same with the intermediate system exposed, for the residual / energy-balance checks of the tests:
+   lhs [ncols][21][5], rhs [ncols][21] (right-hand side before the solve), sol [ncols][21], cv [ncols][20],
+   hs [ncols][4] = {hs_soil, hs_h2osfc, hs_top_snow, dhsdT}; any pointer may be NULL */
+void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs, double *rhs, double *sol, double *cv, double *hs);
+/* probes matching ref_harness.cc (the parts of this path the reference's headers build for) */
+void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out);
+void elmo_pdma(int64_t n, const int *snl, const double *lhs, double *rhs);
+void elmo_phase_change(elmo_state *S, double dt, const double *dhsdT, const double *c_h2osfc);
 void elmo_timestep7(elmo_state *S, double dt);            /* elm_kokkos_interface.cc:289-307 order */
 
 /* ---- L2 physics, one column (elmo_physics.c) ---- */
@@ -349,6 +363,49 @@ void elmo_cf_compute_flux(const elmo_land *L, double dtime, int snl, int frac_ve
                           double *eflx_sh_soil, double *eflx_sh_h2osfc, double *qflx_evap_soi, double *qflx_ev_snow,
                           double *qflx_ev_soil, double *qflx_ev_h2osfc, double *dlrad, double *ulrad, double *cgrnds,
                           double *cgrndl, double *cgrnd, double *t_ref2m, double *q_ref2m, double *rh_ref2m);
+
+/* soil / snow temperature (elmo_physics_d.c) */
+void elmo_st_calc_soil_tk(int ltype, const double *h2osoi_liq, const double *h2osoi_ice, const double *t_soisno,
+                          const double *dz, const double *watsat, const double *tkmg, const double *tkdry, double *thk);
+void elmo_st_calc_snow_tk(int snl, double frac_sno, const double *h2osoi_liq, const double *h2osoi_ice,
+                          const double *dz, double *thk);
+void elmo_st_calc_face_tk(int snl, const double *thk, const double *z, const double *zi, double *tk);
+void elmo_st_calc_soil_heat_capacity(int ltype, int snl, double h2osno, const double *watsat, const double *h2osoi_ice,
+                                     const double *h2osoi_liq, const double *dz, const double *csol, double *cv);
+void elmo_st_calc_snow_heat_capacity(int snl, double frac_sno, const double *h2osoi_ice, const double *h2osoi_liq,
+                                     double *cv);
+double elmo_st_calc_h2osfc_tk(double h2osfc, const double *thk, const double *z);
+double elmo_st_calc_h2osfc_heat_capacity(int snl, double h2osfc, double frac_h2osfc);
+double elmo_st_calc_h2osfc_height(int snl, double h2osfc, double frac_h2osfc);
+double elmo_st_calc_surface_heat_flux(int frac_veg_nosno, double dlrad, double emg, double forc_lwrad, double htvp,
+                                      double solar_abg, double temp, double eflx_sh, double qflx_ev);
+double elmo_st_calc_dhsdT(double cgrnd, double emg, double t_grnd);
+double elmo_st_check_absorbed_solar(double frac_sno_eff, double sabg_snow, double sabg_soil);
+void elmo_st_calc_diffusive_heat_flux(int snl, const double *tk, const double *t_soisno, const double *z, double *fn);
+void elmo_st_calc_heat_flux_matrix_factor(int snl, double dtime, const double *cv, const double *dz, const double *z,
+                                          const double *zi, double *fact);
+void elmo_st_update_temperature(int snl, double frac_h2osfc, const double *tvector, double *t_h2osfc, double *t_soisno);
+void elmo_st_update_t_grnd(int snl, double frac_h2osfc, double frac_sno_eff, double t_h2osfc, const double *t_soisno,
+                           double *t_grnd);
+void elmo_st_set_rhs(double dtime, int snl, double hs_top_snow, double dhsdT, double hs_soil, double frac_sno_eff,
+                     const double *t_soisno, const double *fact, const double *fn, const double *sabg_lyr,
+                     const double *z, double tk_h2osfc, double t_h2osfc, double dz_h2osfc, double c_h2osfc,
+                     double hs_h2osfc, double *rhs_vec);
+void elmo_st_set_lhs(double dtime, int snl, double dz_h2osfc, double c_h2osfc, double tk_h2osfc, double frac_h2osfc,
+                     double frac_sno_eff, double dhsdT, const double *z, const double *fact, const double *tk,
+                     double *lhs);
+void elmo_st_pdma(int snl, const double *LHS, double *A, double *B, double *Z, double *RHS);
+void elmo_st_phase_change_h2osfc(int snl, double dtime, double frac_sno, double frac_h2osfc, double dhsdT,
+                                 double c_h2osfc, double fact_sl1, double *t_h2osfc, double *h2osfc,
+                                 double *xmf_h2osfc, double *qflx_h2osfc_to_ice, double *eflx_h2osfc_to_snow,
+                                 double *h2osno, double *int_snow, double *snow_depth, double *h2osoi_ice_sl1,
+                                 double *t_soisno_sl1);
+void elmo_st_phase_change_soisno(int snl, int ltype, double dtime, double dhsdT, double frac_h2osfc,
+                                 double frac_sno_eff, const double *fact, const double *watsat, const double *sucsat,
+                                 const double *bsw, const double *dz, double *h2osno, double *snow_depth, double *xmf,
+                                 double *qflx_snofrz, double *qflx_snow_melt, double *qflx_snomelt,
+                                 double *eflx_snomelt, int *imelt, double *qflx_snofrz_lyr, double *h2osoi_ice,
+                                 double *h2osoi_liq, double *t_soisno);
 
 /* surface albedo (surface_albedo_impl.hh) */
 void elmo_sa_init_timestep(int urbpoi, double elai, const double *mss_cnc_bcphi, const double *mss_cnc_bcpho,

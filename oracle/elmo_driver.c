@@ -372,6 +372,126 @@ void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha
 }
 
 /* elm_kokkos_interface.cc:289-307 */
+/* soil_temperature_kokkos.cc:6-278.  The wrapper's "dummy ltype" (:77-79) is 1 (istsoil) for every column. */
+void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs_out, double *rhs_out, double *sol_out,
+                              double *cv_out, double *hs_out)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int ltype = 1;
+    const int snl = S->snl[c];
+    const int nlevsno = ELMO_NLEVSNO;
+    double thk[20], tk[20], cv[20], fn[20];
+    /* soil_thermal_props (:92-104) */
+    elmo_st_calc_soil_tk(ltype, LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(dz, 20), LV(watsat, 15),
+                         LV(tkmg, 15), LV(tkdry, 15), thk);
+    elmo_st_calc_snow_tk(snl, S->frac_sno[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(dz, 20), thk);
+    elmo_st_calc_face_tk(snl, thk, LV(zsoi, 20), LV(zisoi, 21), tk);
+    elmo_st_calc_soil_heat_capacity(ltype, snl, S->h2osno[c], LV(watsat, 15), LV(h2osoi_ice, 20), LV(h2osoi_liq, 20),
+                                    LV(dz, 20), LV(csol, 20), cv);
+    elmo_st_calc_snow_heat_capacity(snl, S->frac_sno[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), cv);
+    const double tk_h2osfc = elmo_st_calc_h2osfc_tk(S->h2osfc[c], thk, LV(zsoi, 20));
+    const double c_h2osfc = elmo_st_calc_h2osfc_heat_capacity(snl, S->h2osfc[c], S->frac_h2osfc[c]);
+    const double dz_h2osfc = elmo_st_calc_h2osfc_height(snl, S->h2osfc[c], S->frac_h2osfc[c]);
+    /* surface_heat_fluxes (:121-142) */
+    const int soitop = nlevsno;
+    const int snotop = nlevsno - snl;
+    S->sabg_chk[c] = elmo_st_check_absorbed_solar(S->frac_sno_eff[c], S->sabg_snow[c], S->sabg_soil[c]);
+    const double hs_soil =
+        elmo_st_calc_surface_heat_flux(S->frac_veg_nosno[c], S->dlrad[c], S->emg[c], S->forc_lwrad[c], S->htvp[c],
+                                       S->sabg_soil[c], LV(t_soisno, 20)[soitop], S->eflx_sh_soil[c], S->qflx_ev_soil[c]);
+    const double hs_h2osfc =
+        elmo_st_calc_surface_heat_flux(S->frac_veg_nosno[c], S->dlrad[c], S->emg[c], S->forc_lwrad[c], S->htvp[c],
+                                       S->sabg_soil[c], S->t_h2osfc[c], S->eflx_sh_h2osfc[c], S->qflx_ev_h2osfc[c]);
+    const double hs_top_snow =
+        elmo_st_calc_surface_heat_flux(S->frac_veg_nosno[c], S->dlrad[c], S->emg[c], S->forc_lwrad[c], S->htvp[c],
+                                       LV(sabg_lyr, 6)[snotop], LV(t_soisno, 20)[snotop], S->eflx_sh_snow[c],
+                                       S->qflx_ev_snow[c]);
+    const double dhsdT = elmo_st_calc_dhsdT(S->cgrnd[c], S->emg[c], S->t_grnd[c]);
+    /* diffusive_heat_flux (:153-170) */
+    elmo_st_calc_diffusive_heat_flux(snl, tk, LV(t_soisno, 20), LV(zsoi, 20), fn);
+    elmo_st_calc_heat_flux_matrix_factor(snl, dt, cv, LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), LV(fact, 20));
+    /* set_RHS / set_LHS (:181-185) */
+    double rhs[21], lhs[21 * 5];
+    elmo_st_set_rhs(dt, snl, hs_top_snow, dhsdT, hs_soil, S->frac_sno_eff[c], LV(t_soisno, 20), LV(fact, 20), fn,
+                    LV(sabg_lyr, 6), LV(zsoi, 20), tk_h2osfc, S->t_h2osfc[c], dz_h2osfc, c_h2osfc, hs_h2osfc, rhs);
+    elmo_st_set_lhs(dt, snl, dz_h2osfc, c_h2osfc, tk_h2osfc, S->frac_h2osfc[c], S->frac_sno_eff[c], dhsdT, LV(zsoi, 20),
+                    LV(fact, 20), tk, lhs);
+    if (lhs_out) memcpy(lhs_out + (size_t)c * 105, lhs, sizeof lhs);
+    if (rhs_out) memcpy(rhs_out + (size_t)c * 21, rhs, sizeof rhs);
+    if (cv_out) memcpy(cv_out + (size_t)c * 20, cv, sizeof cv);
+    if (hs_out) {
+      hs_out[(size_t)c * 4 + 0] = hs_soil;
+      hs_out[(size_t)c * 4 + 1] = hs_h2osfc;
+      hs_out[(size_t)c * 4 + 2] = hs_top_snow;
+      hs_out[(size_t)c * 4 + 3] = dhsdT;
+    }
+    /* solve (:215-225): A, B, Z are freshly zero-allocated Views */
+    double A[20] = {0}, B[19] = {0}, Z[21] = {0};
+    elmo_st_pdma(snl, lhs, A, B, Z, rhs);
+    if (sol_out) memcpy(sol_out + (size_t)c * 21, rhs, sizeof rhs);
+    /* update_temperature (:232-237) */
+    elmo_st_update_temperature(snl, S->frac_h2osfc[c], rhs, &S->t_h2osfc[c], LV(t_soisno, 20));
+    /* phase change (:245-266) */
+    elmo_st_phase_change_h2osfc(snl, dt, S->frac_sno[c], S->frac_h2osfc[c], dhsdT, c_h2osfc, LV(fact, 20)[nlevsno - 1],
+                                &S->t_h2osfc[c], &S->h2osfc[c], &S->xmf_h2osfc[c], &S->qflx_h2osfc_ice[c],
+                                &S->eflx_h2osfc_snow[c], &S->h2osno[c], &S->int_snow[c], &S->snow_depth[c],
+                                &LV(h2osoi_ice, 20)[nlevsno - 1], &LV(t_soisno, 20)[nlevsno - 1]);
+    elmo_st_phase_change_soisno(snl, ltype, dt, dhsdT, S->frac_h2osfc[c], S->frac_sno_eff[c], LV(fact, 20),
+                                LV(watsat, 15), LV(sucsat, 15), LV(bsw, 15), LV(dz, 20), &S->h2osno[c],
+                                &S->snow_depth[c], &S->xmf[c], &S->qflx_snofrz[c], &S->qflx_snow_melt[c],
+                                &S->qflx_snomelt[c], &S->eflx_snomelt[c], LV(imelt, 20), LV(qflx_snofrz_lyr, 5),
+                                LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20));
+    /* update_t_grnd (:275-280) */
+    elmo_st_update_t_grnd(snl, S->frac_h2osfc[c], S->frac_sno_eff[c], S->t_h2osfc[c], LV(t_soisno, 20), &S->t_grnd[c]);
+  }
+}
+
+void elmo_soil_temperature(elmo_state *S, double dt) { elmo_soil_temperature_ex(S, dt, NULL, NULL, NULL, NULL, NULL); }
+
+/* counterparts of the ref_harness.cc probes elmref_soil_thermal / elmref_pdma / elmref_phase_change */
+void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out)
+{
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int ltype = 1;
+    double *thk = thk_out + (size_t)c * 20, *tk = tk_out + (size_t)c * 20, *cv = cv_out + (size_t)c * 20;
+    elmo_st_calc_soil_tk(ltype, LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(dz, 20), LV(watsat, 15),
+                         LV(tkmg, 15), LV(tkdry, 15), thk);
+    elmo_st_calc_snow_tk(S->snl[c], S->frac_sno[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(dz, 20), thk);
+    elmo_st_calc_face_tk(S->snl[c], thk, LV(zsoi, 20), LV(zisoi, 21), tk);
+    elmo_st_calc_soil_heat_capacity(ltype, S->snl[c], S->h2osno[c], LV(watsat, 15), LV(h2osoi_ice, 20),
+                                    LV(h2osoi_liq, 20), LV(dz, 20), LV(csol, 20), cv);
+    elmo_st_calc_snow_heat_capacity(S->snl[c], S->frac_sno[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), cv);
+    scal_out[c * 3 + 0] = elmo_st_calc_h2osfc_tk(S->h2osfc[c], thk, LV(zsoi, 20));
+    scal_out[c * 3 + 1] = elmo_st_calc_h2osfc_heat_capacity(S->snl[c], S->h2osfc[c], S->frac_h2osfc[c]);
+    scal_out[c * 3 + 2] = elmo_st_calc_h2osfc_height(S->snl[c], S->h2osfc[c], S->frac_h2osfc[c]);
+  }
+}
+
+void elmo_pdma(int64_t n, const int *snl, const double *lhs, double *rhs)
+{
+  for (int64_t c = 0; c < n; c++) {
+    double A[20] = {0}, B[19] = {0}, Z[21] = {0};
+    elmo_st_pdma(snl[c], lhs + (size_t)c * 105, A, B, Z, rhs + (size_t)c * 21);
+  }
+}
+
+void elmo_phase_change(elmo_state *S, double dt, const double *dhsdT, const double *c_h2osfc)
+{
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int ltype = 1;
+    elmo_st_phase_change_h2osfc(S->snl[c], dt, S->frac_sno[c], S->frac_h2osfc[c], dhsdT[c], c_h2osfc[c],
+                                LV(fact, 20)[4], &S->t_h2osfc[c], &S->h2osfc[c], &S->xmf_h2osfc[c],
+                                &S->qflx_h2osfc_ice[c], &S->eflx_h2osfc_snow[c], &S->h2osno[c], &S->int_snow[c],
+                                &S->snow_depth[c], &LV(h2osoi_ice, 20)[4], &LV(t_soisno, 20)[4]);
+    elmo_st_phase_change_soisno(S->snl[c], ltype, dt, dhsdT[c], S->frac_h2osfc[c], S->frac_sno_eff[c], LV(fact, 20),
+                                LV(watsat, 15), LV(sucsat, 15), LV(bsw, 15), LV(dz, 20), &S->h2osno[c],
+                                &S->snow_depth[c], &S->xmf[c], &S->qflx_snofrz[c], &S->qflx_snow_melt[c],
+                                &S->qflx_snomelt[c], &S->eflx_snomelt[c], LV(imelt, 20), LV(qflx_snofrz_lyr, 5),
+                                LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20));
+  }
+}
+
 void elmo_timestep7(elmo_state *S, double dt)
 {
   elmo_frac_wet(S);

@@ -71,6 +71,11 @@ class _Lib:
         L.elmo_canopy_fluxes_given.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 4
         L.elmo_bareground_fluxes_given.argtypes = [C.c_void_p, C.c_void_p]
         L.elmo_albedo_snicar_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elmo_soil_temperature.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
+        L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
+        L.elmo_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
+        L.elmo_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         self.ref = _load(os.path.join(HERE, "_ref", "libelmref.so"))
         if self.ref is not None:
             R = self.ref
@@ -81,6 +86,10 @@ class _Lib:
             R.elmref_qsat.argtypes = [C.c_int64] + [C.c_void_p] * 6
             R.elmref_forc_derived.argtypes = [C.c_int64] + [C.c_void_p] * 6
             R.elmref_friction.argtypes = [C.c_int64] + [C.c_void_p] * 12
+            if hasattr(R, "elmref_soil_thermal"):
+                R.elmref_soil_thermal.argtypes = [C.c_void_p] * 5
+                R.elmref_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
+                R.elmref_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
 
 
 _LIB = None
@@ -226,6 +235,43 @@ class OracleState:
 
     def timestep7(self, dt):
         self._L.lib.elmo_timestep7(self.ptr, float(dt))
+
+    # -- next row: soil / snow temperature (soil_temperature_kokkos.cc) ----------------------------
+    def soil_temperature(self, dt):
+        self._L.lib.elmo_soil_temperature(self.ptr, float(dt))
+
+    def soil_temperature_ex(self, dt):
+        """-> dict(lhs [n,21,5], rhs [n,21] before the solve, sol [n,21], cv [n,20], hs [n,4] = hs_soil, hs_h2osfc,
+        hs_top_snow, dhsdT): the wrapper-local system of each column."""
+        n = self.ncols
+        out = dict(lhs=np.zeros((n, 21, 5)), rhs=np.zeros((n, 21)), sol=np.zeros((n, 21)), cv=np.zeros((n, 20)),
+                   hs=np.zeros((n, 4)))
+        self._L.lib.elmo_soil_temperature_ex(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "sol", "cv", "hs")])
+        return out
+
+    def soil_thermal(self, lib=None):
+        """-> (thk, tk, cv [n,20], scal [n,3] = tk_h2osfc, c_h2osfc, dz_h2osfc); lib: the Reference's library instead."""
+        n = self.ncols
+        thk, tk, cv, scal = np.zeros((n, 20)), np.zeros((n, 20)), np.zeros((n, 20)), np.zeros((n, 3))
+        fn = self._L.lib.elmo_soil_thermal if lib is None else lib.elmref_soil_thermal
+        fn(self.ptr, thk.ctypes.data, tk.ctypes.data, cv.ctypes.data, scal.ctypes.data)
+        return thk, tk, cv, scal
+
+    def phase_change(self, dt, dhsdT, c_h2osfc, lib=None):
+        a = np.ascontiguousarray(dhsdT, dtype=np.float64)
+        b = np.ascontiguousarray(c_h2osfc, dtype=np.float64)
+        fn = self._L.lib.elmo_phase_change if lib is None else lib.elmref_phase_change
+        fn(self.ptr, float(dt), a.ctypes.data, b.ctypes.data)
+
+
+def pdma(snl, lhs, rhs, lib=None):
+    """Solve the pentadiagonal systems (lhs [n,21,5], rhs [n,21]) -> solution [n,21]; lib: the Reference's library."""
+    snl = np.ascontiguousarray(snl, dtype=np.int32)
+    lhs = np.ascontiguousarray(lhs, dtype=np.float64)
+    sol = np.array(rhs, dtype=np.float64, order="C", copy=True)
+    fn = globals()["lib"]().lib.elmo_pdma if lib is None else lib.elmref_pdma
+    fn(snl.shape[0], snl.ctypes.data, lhs.ctypes.data, sol.ctypes.data)
+    return sol
 
 
 def set_pft_tables(psn, alb, z0mr, displar, pft):

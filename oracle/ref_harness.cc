@@ -8,6 +8,7 @@
 // Covered: every hot-path header that compiles without netcdf-c:
 //   canopy_hydrology.h  surface_radiation.h  canopy_temperature.h (+qsat.h, surface_resistance.h)
 //   bareground_fluxes.h (+friction_velocity.h)  snow_snicar.h  soil_moist_stress.h  atm_physics.h
+//   soil_thermal_properties.h  pentadiagonal_solver.h  phase_change.h
 // Not covered (unbuildable here: pft_data.h -> read_input.hh -> read_netcdf.hh -> netcdf.h):
 //   canopy_fluxes.h  photosynthesis.h  surface_albedo.h
 // The loops below follow the argument wiring of driver/kokkos/*_kokkos.cc (cited per function).
@@ -25,6 +26,11 @@
 #include "snow_snicar.h"
 #include "soil_moist_stress.h"
 #include "surface_radiation.h"
+// soil / snow temperature: the headers that build without Kokkos (soil_temperature.h, soil_temp_rhs.h and
+// soil_temp_lhs.h include invoke_kernel.hh, whose serial branch does not compile)
+#include "pentadiagonal_solver.h"
+#include "phase_change.h"
+#include "soil_thermal_properties.h"
 
 #include "elm_oracle.h"
 
@@ -307,4 +313,56 @@ void elmref_friction(int64_t n, const double* ur, const double* thv, const doubl
   }
 }
 
+
+// soil_temperature_kokkos.cc:92-104: the soil_thermal_props lambda (dummy ltype 1, :77-79).
+// thk/tk/cv [ncols][20], scal [ncols][3] = {tk_h2osfc, c_h2osfc, dz_h2osfc}
+void elmref_soil_thermal(elmo_state* S, double* thk_out, double* tk_out, double* cv_out, double* scal_out)
+{
+  const int n = (int)S->ncols;
+  AD2 h2osoi_liq(n, 20, S->h2osoi_liq), h2osoi_ice(n, 20, S->h2osoi_ice), t_soisno(n, 20, S->t_soisno), dz(n, 20, S->dz);
+  AD2 watsat(n, 15, S->watsat), tkmg(n, 15, S->tkmg), tkdry(n, 15, S->tkdry), csol(n, 20, S->csol);
+  AD2 zsoi(n, 20, S->zsoi), zisoi(n, 21, S->zisoi);
+  AD2 thk(n, 20, thk_out), tk(n, 20, tk_out), cv(n, 20, cv_out);
+  for (int c = 0; c < n; c++) {
+    const int ltype = 1;
+    ELM::soil_thermal::calc_soil_tk(c, ltype, h2osoi_liq, h2osoi_ice, t_soisno, dz, watsat, tkmg, tkdry, thk);
+    ELM::soil_thermal::calc_snow_tk(c, S->snl[c], S->frac_sno[c], h2osoi_liq, h2osoi_ice, dz, thk);
+    ELM::soil_thermal::calc_face_tk(c, S->snl[c], thk, zsoi, zisoi, tk);
+    ELM::soil_thermal::calc_soil_heat_capacity(c, ltype, S->snl[c], S->h2osno[c], watsat, h2osoi_ice, h2osoi_liq, dz, csol,
+                                               cv);
+    ELM::soil_thermal::calc_snow_heat_capacity(c, S->snl[c], S->frac_sno[c], h2osoi_ice, h2osoi_liq, cv);
+    scal_out[c * 3 + 0] = ELM::soil_thermal::calc_h2osfc_tk(c, S->h2osfc[c], thk, zsoi);
+    scal_out[c * 3 + 1] = ELM::soil_thermal::calc_h2osfc_heat_capacity(S->snl[c], S->h2osfc[c], S->frac_h2osfc[c]);
+    scal_out[c * 3 + 2] = ELM::soil_thermal::calc_h2osfc_height(S->snl[c], S->h2osfc[c], S->frac_h2osfc[c]);
+  }
+}
+
+// soil_temperature_kokkos.cc:215-225: solver::PDMA on given systems; lhs [n][21][5], rhs [n][21] (solution on return)
+void elmref_pdma(int64_t n_, int* snl, double* lhs, double* rhs)
+{
+  const int n = (int)n_;
+  AI1 snl_(n, snl);
+  AD3 LHS(n, 21, 5, lhs);
+  AD2 A(n, 20, 0.0), B(n, 19, 0.0), Z(n, 21, 0.0);
+  AD2 RHS(n, 21, rhs);
+  for (int c = 0; c < n; c++) ELM::solver::PDMA(c, snl_, LHS, A, B, Z, RHS);
+}
+
+// soil_temperature_kokkos.cc:245-266: the phase_change lambda, with the wrapper-local dhsdT / c_h2osfc given
+void elmref_phase_change(elmo_state* S, double dt, const double* dhsdT, const double* c_h2osfc)
+{
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int ltype = 1;
+    double* fact = S->fact + (size_t)c * 20;
+    ELM::soil_temp::phase_change_h2osfc(S->snl[c], dt, S->frac_sno[c], S->frac_h2osfc[c], dhsdT[c], c_h2osfc[c], fact[4],
+                                        S->t_h2osfc[c], S->h2osfc[c], S->xmf_h2osfc[c], S->qflx_h2osfc_ice[c],
+                                        S->eflx_h2osfc_snow[c], S->h2osno[c], S->int_snow[c], S->snow_depth[c],
+                                        S->h2osoi_ice[(size_t)c * 20 + 4], S->t_soisno[(size_t)c * 20 + 4]);
+    ELM::soil_temp::phase_change_soisno(S->snl[c], ltype, dt, dhsdT[c], S->frac_h2osfc[c], S->frac_sno_eff[c], V(fact, 20),
+                                        V(watsat, 15), V(sucsat, 15), V(bsw, 15), V(dz, 20), S->h2osno[c], S->snow_depth[c],
+                                        S->xmf[c], S->qflx_snofrz[c], S->qflx_snow_melt[c], S->qflx_snomelt[c],
+                                        S->eflx_snomelt[c], AI1(20, S->imelt + (size_t)c * 20), V(qflx_snofrz_lyr, 5),
+                                        V(h2osoi_ice, 20), V(h2osoi_liq, 20), V(t_soisno, 20));
+  }
+}
 } // extern "C"

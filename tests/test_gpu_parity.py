@@ -284,3 +284,31 @@ def test_results_do_not_depend_on_the_schedule():
         for k, v in outs[0].items():
             assert np.array_equal(v, outs[rep][k], equal_nan=True), (rep, k)
     D.close()
+
+
+@pytest.mark.parametrize("tier,n,seed", [("A", 4700, 31), ("B", 20000, 32), ("B", 1001, 33)])
+def test_soil_temperature_next_row(tier, n, seed):
+    """kokkos_soil_temperature (the next call of ELMInterface::advance after the seven): thermal properties, the
+    21-row pentadiagonal temperature system, its solve, phase change and ground temperature, on bit-identical inputs
+    (the device state is re-synchronised from the oracle after the seven wrappers)."""
+    D, S = _pair(n, tier, seed)
+    st.timestep7(D, DT)
+    S.timestep7(DT)
+    for k, v in S.fields.items():
+        if k != "err_flags":
+            D[k] = v
+    st.kokkos_soil_temperature(D, DT)
+    S.soil_temperature(DT)
+    names = ["t_soisno", "t_h2osfc", "t_grnd", "h2osoi_ice", "h2osoi_liq", "h2osfc", "h2osno", "int_snow", "snow_depth",
+             "fact", "sabg_chk", "xmf", "xmf_h2osfc", "qflx_h2osfc_ice", "eflx_h2osfc_snow", "qflx_snofrz", "qflx_snow_melt",
+             "qflx_snomelt", "eflx_snomelt", "qflx_snofrz_lyr", "imelt"]
+    worst, bad = H.compare_states(D, S, names=names, extra_scale=H.PHASE_CHANGE_SCALE)
+    assert not bad, f"soil_temperature {tier}/{n}: worst rel err {worst:.3e}; over tolerance: {bad}"
+    # nothing else was touched
+    others = [k for k in S.fields if k not in names and k != "err_flags"]
+    worst, bad = H.compare_states(D, S, names=others, rel=0.0, newton=False)
+    assert not bad, bad
+    if tier == "B":
+        im = np.bincount(D["imelt"].ravel(), minlength=3)
+        assert im[1] > 0 and im[2] > 0 and set(np.unique(D["snl"])) == {0, 1, 2, 3, 4, 5}
+    D.close()

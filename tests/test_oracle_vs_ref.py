@@ -186,3 +186,57 @@ def test_friction_velocity_bit_exact_vs_reference():
     # every branch of the profile functions was taken (zeta < -zetat, < 0, <= 1, > 1)
     zeta = (kw["hgt_t"] - kw["displa"]) / ref[:, 1]
     assert (zeta < -0.465).any() and ((zeta < 0) & (zeta >= -0.465)).any() and ((zeta >= 0) & (zeta <= 1)).any() and (zeta > 1).any()
+
+
+# ---- next row: soil / snow temperature (soil_temperature_kokkos.cc).  The reference headers that build without
+# Kokkos - soil_thermal_properties.h, pentadiagonal_solver.h, phase_change.h - against their restatements.
+@pytest.fixture(scope="module")
+def soil_states():
+    ft = H.field_table_from_oracle()
+    cols, scal, soil = synth.make_state(ft, 6000, tier="B", seed=77)
+    S = H.oracle_state(cols, scal, soil)
+    S.timestep7(1800.0)  # realistic fluxes / radiation for the surface heat flux terms
+    return S
+
+
+def test_soil_thermal_properties_bitwise(soil_states):
+    S = soil_states
+    got = S.soil_thermal()
+    ref = S.soil_thermal(lib=O.Reference().R)
+    for name, a, b in zip(("thk", "tk", "cv", "tk_h2osfc/c_h2osfc/dz_h2osfc"), got, ref):
+        assert np.array_equal(a, b, equal_nan=True), name
+    assert (got[0][:, 5:] > 0).all() and (got[2][:, 5:] > 0).all()
+    snow = np.arange(5)[None, :] >= 5 - S["snl"][:, None]
+    assert (got[0][:, :5][snow] > 0).all() and (got[0][:, :5][~snow] == 0).all()
+
+
+def test_pentadiagonal_solver_bitwise(soil_states):
+    S = soil_states.clone()
+    ex = S.soil_temperature_ex(1800.0)
+    a = O.pdma(soil_states["snl"], ex["lhs"], ex["rhs"])
+    b = O.pdma(soil_states["snl"], ex["lhs"], ex["rhs"], lib=O.Reference().R)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, ex["sol"], equal_nan=True)
+    assert set(np.unique(soil_states["snl"])) == {0, 1, 2, 3, 4, 5}  # every system size 16..21 was solved
+
+
+def test_phase_change_bitwise(soil_states):
+    S = soil_states
+    base = S.clone()
+    ex = base.soil_temperature_ex(1800.0)  # leaves the matrix factor `fact` in the state
+    c_h2osfc = S.soil_thermal()[3][:, 1]
+
+    def prepared():
+        rng = np.random.default_rng(9)
+        T = S.clone()
+        T["fact"][...] = base["fact"]
+        T["t_soisno"][...] = np.where(S["t_soisno"] > 0, S["t_soisno"] + rng.uniform(-3, 3, S["t_soisno"].shape), 0)
+        T["t_h2osfc"][...] = S["t_h2osfc"] + rng.uniform(-4, 2, S.ncols)
+        return T
+
+    A, B = prepared(), prepared()
+    A.phase_change(1800.0, ex["hs"][:, 3], c_h2osfc)
+    B.phase_change(1800.0, ex["hs"][:, 3], c_h2osfc, lib=O.Reference().R)
+    assert not _same(A, B)
+    im = np.bincount(A["imelt"].ravel(), minlength=3)
+    assert im[1] > 1000 and im[2] > 1000 and (A["qflx_h2osfc_ice"] != 0).sum() > 100  # melting, freezing, pond freezing
+    assert (A["qflx_snomelt"] > 0).any() and (A["qflx_snofrz"] > 0).any()

@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from elmkernels_amd import state as st  # noqa: E402
 
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-D, _ = bench.build_state(cols, 0, "B", 0x5EEDE1A0)
+D, _ = bench.build_state(cols, 0, os.environ.get("CF_TIER", "B"), 0x5EEDE1A0)
 for _ in range(int(os.environ.get('CF_WARM', '2'))):
     D.restore_fields()
     st.timestep7(D, 1800.0)

@@ -181,7 +181,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t pos_bytes = align_up((size_t)ctx->ld * 4, 256);
   const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes;
+  const size_t stw_bytes = align_up((size_t)63 * (size_t)ctx->ld * 8, 256);
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes + stw_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -221,6 +222,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     h.cf_blk = (uint32_t*)q;
     q += blk_bytes;
     h.alb_snow = (double*)q;
+    q += snow_bytes;
+    h.st_work = (double*)q;
     h.cf_nblk = cf_nblk;
   }
   {

@@ -12,8 +12,13 @@
 //   soil_temp::phase_change_h2osfc :11, phase_change_soisno :182   (src/physics/phase_change_impl.hh)
 //
 // The reference runs nine parallel_for launches and materialises tk, cv, fn, rhs[21], lhs[21][5], A, B, Z and ten
-// more scratch Views in memory.  Here one thread owns one column: the 21-row, 5-band system (snow layers, standing
-// surface water, soil layers) is assembled, solved and applied in registers, every array statically indexed.
+// more scratch Views in memory.  Here one thread owns one column and goes down it once: the thermal properties of a
+// level, its matrix factor, the diffusive fluxes across its faces and its row of the 21-row, 5-band system (snow
+// layers, standing surface water, soil layers) are formed from a sliding window of three levels and pushed straight
+// into the forward sweep; back substitution and phase change (its three loops fused level by level) follow, level by
+// level.  All level loops are rolled - the level index is the same for every lane, so its branches are uniform and
+// every access is a coalesced row of the SoA state - and the sweep's A, B, Z (63 doubles per column) go through the
+// context's scratch instead of a register array, which keeps the kernel small enough for several waves per SIMD.
 // The number of active snow layers differs from lane to lane, so loops that the reference starts at the top active
 // layer run over all rows with a predicate, and rows above the snow pack enter the forward sweep as identity rows:
 // with their A, B, Z equal to zero the general recurrence reproduces the reference's special first and second rows
@@ -46,91 +51,111 @@ __device__ __forceinline__ double st_surface_heat_flux(int frac_veg_nosno, doubl
          (eflx_sh + qflx_ev * htvp);
 }
 
+// thermal conductivity and heat capacity of level i (soil_thermal_properties_impl.hh: calc_soil_tk :20 and
+// calc_soil_heat_capacity :163 with the wrapper's ltype == 1, calc_snow_tk :96, calc_snow_heat_capacity :206).
+// i is the same for every lane (the level loops are rolled), so the branches on it are uniform.
+__device__ __forceinline__ void st_level_props(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int i,
+                                               const int top, const int snl, const double frac_sno, const double h2osno,
+                                               double& thk, double& cv)
+{
+  const double liq = LV(h2osoi_liq, i), ice = LV(h2osoi_ice, i), dzl = LV(dz, i);
+  if (i >= NLEVSNO) {
+    const int j = i - NLEVSNO;
+    const double watsat = LV(watsat, j);
+    double satw = (liq / DENH2O + ice / DENICE) / (dzl * watsat);
+    satw = dmin(1.0, satw);
+    const double tkdry = LV(tkdry, j);
+    if (satw > 1.0e-6) {
+      double dke;
+      if (LV(t_soisno, i) >= TFRZ) {
+        dke = dmax(0.0, log10(satw) + 1.0);
+      } else {
+        dke = satw;
+      }
+      const double fl = (liq / (DENH2O * dzl)) / (liq / (DENH2O * dzl) + ice / (DENICE * dzl));
+      const double dksat = LV(tkmg, j) * pow(ST_TKWAT, fl * watsat) * pow(ST_TKICE, (1.0 - fl) * watsat);
+      thk = dke * dksat + (1.0 - dke) * tkdry;
+    } else {
+      thk = tkdry;
+    }
+    if (i >= NLEVSNO + NLEVBED) thk = ST_TKBDRK;
+    cv = LV(csol, i) * (1.0 - watsat) * dzl + (ice * ST_CPICE + liq * ST_CPWAT);
+    if (i == NLEVSNO && snl == 0 && h2osno > 0.0) cv += ST_CPICE * h2osno;
+  } else {
+    if (i < top) {
+      thk = 0.0;
+      cv = 0.0;
+    } else {
+      const double bw = (ice + liq) / (frac_sno * dzl);
+      thk = ST_TKAIR + (7.75e-5 * bw + 1.105e-6 * bw * bw) * (ST_TKICE - ST_TKAIR);
+      if (frac_sno > 0.0) {
+        cv = dmax(ST_THIN_SFCLAYER, (ST_CPWAT * liq + ST_CPICE * ice) / frac_sno);
+      } else {
+        cv = ST_THIN_SFCLAYER;
+      }
+    }
+  }
+}
+
+// state of the forward sweep of solver::PDMA (pentadiagonal_solver_impl.hh:16-76).  A, B, Z of every row go to the
+// context's scratch (SoA [row][column] like the state: the row loops are rolled, a register array would need dynamic
+// indexing); the recurrence itself only needs the last two rows, kept here.
+struct StSweep {
+  double* __restrict__ A;  // scratch bases of this column; element of row r at [r * ld]
+  double* __restrict__ B;
+  double* __restrict__ Z;
+  double Am2, Am1, Bm2, Bm1, Zm2, Zm1;
+  double Y1, U1, r19, l4_19, A19;  // kept from the second row from the bottom for the reference's form of the last two
+};
+
+// one row of the forward sweep.  Rows above the snow pack arrive as identity rows; with their A, B, Z equal to zero
+// the general recurrence gives the reference's special first and second rows exactly.
+__device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const int r, const double l0, const double l1,
+                                            const double l2, const double l3, const double l4, const double rr)
+{
+  constexpr int N = NROW;
+  if (r < N - 2) {
+    const double Y1 = l3 - w.Am2 * l4;
+    const double U1 = 1.0 / (l2 - w.Bm2 * l4 - w.Am1 * Y1);
+    const double a = (l1 - w.Bm1 * Y1) * U1;
+    const double b = l0 * U1;
+    const double z = (rr - w.Zm2 * l4 - w.Zm1 * Y1) * U1;
+    w.A[(int64_t)r * ld] = a;
+    w.B[(int64_t)r * ld] = b;
+    w.Z[(int64_t)r * ld] = z;
+    w.Am2 = w.Am1;
+    w.Am1 = a;
+    w.Bm2 = w.Bm1;
+    w.Bm1 = b;
+    w.Zm2 = w.Zm1;
+    w.Zm1 = z;
+  } else if (r == N - 2) {  // (:55-58); Am1 = A(N-3), Am2 = A(N-4) here, likewise B
+    w.Y1 = l3 - w.Am2 * l4;
+    w.U1 = 1.0 / (l2 - w.Bm2 * l4 - w.Am1 * w.Y1);
+    w.A19 = (l1 - w.Bm1 * w.Y1) * w.U1;
+    w.r19 = rr;
+    w.l4_19 = l4;
+  } else {  // bottom row (:61-66); Z(N-2) in the reference's own form, with Z(N-3) in both products
+    const double Y2 = l3 - w.Am1 * l4;
+    const double U2 = 1.0 / (l2 - w.Bm1 * l4 - w.A19 * Y2);
+    const double z19 = (w.r19 - w.Zm1 * w.l4_19 - w.Zm1 * w.Y1) * w.U1;
+    const double z20 = (rr - z19 * l4 - z19 * Y2) * U2;
+    w.Zm2 = z19;  // handed to the back substitution
+    w.Zm1 = z20;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
 {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   if (c >= S->ncols) return;
-  const int ltype = 1;  // the wrapper's "dummy ltype" (soil_temperature_kokkos.cc:77-79)
+  // (the wrapper's "dummy ltype" is 1 - istsoil - for every column, soil_temperature_kokkos.cc:77-79)
   const int snl = S->snl[c];
   const int top = NLEVSNO - snl;
   const double frac_sno = S->frac_sno[c], frac_sno_eff = S->frac_sno_eff[c], frac_h2osfc = S->frac_h2osfc[c];
   const double h2osfc0 = S->h2osfc[c], h2osno0 = S->h2osno[c];
-
-  double t[NLEVTOT], z[NLEVTOT], dzl[NLEVTOT], liq[NLEVTOT], ice[NLEVTOT];
-#pragma unroll
-  for (int i = 0; i < NLEVTOT; i++) {
-    t[i] = LV(t_soisno, i);
-    z[i] = LV(zsoi, i);
-    dzl[i] = LV(dz, i);
-    liq[i] = LV(h2osoi_liq, i);
-    ice[i] = LV(h2osoi_ice, i);
-  }
-
-  // ---- soil_thermal_props (:92-104): layer conductivity thk, interface conductivity tk, heat capacity cv
-  double thk[NLEVTOT], cv[NLEVTOT];
-#pragma unroll
-  for (int i = NLEVSNO; i < NLEVTOT; i++) {  // calc_soil_tk, calc_soil_heat_capacity (ltype == 1: soil branch)
-    const double watsat = LV(watsat, i - NLEVSNO);
-    double satw = (liq[i] / DENH2O + ice[i] / DENICE) / (dzl[i] * watsat);
-    satw = dmin(1.0, satw);
-    const double tkdry = LV(tkdry, i - NLEVSNO);
-    if (satw > 1.0e-6) {
-      double dke;
-      if (t[i] >= TFRZ) {
-        dke = dmax(0.0, log10(satw) + 1.0);
-      } else {
-        dke = satw;
-      }
-      const double fl = (liq[i] / (DENH2O * dzl[i])) / (liq[i] / (DENH2O * dzl[i]) + ice[i] / (DENICE * dzl[i]));
-      const double dksat = LV(tkmg, i - NLEVSNO) * pow(ST_TKWAT, fl * watsat) * pow(ST_TKICE, (1.0 - fl) * watsat);
-      thk[i] = dke * dksat + (1.0 - dke) * tkdry;
-    } else {
-      thk[i] = tkdry;
-    }
-    if (i >= NLEVSNO + NLEVBED) thk[i] = ST_TKBDRK;
-    cv[i] = LV(csol, i) * (1.0 - watsat) * dzl[i] + (ice[i] * ST_CPICE + liq[i] * ST_CPWAT);
-    if (i == NLEVSNO && snl == 0 && h2osno0 > 0.0) cv[i] += ST_CPICE * h2osno0;
-  }
-#pragma unroll
-  for (int i = 0; i < NLEVSNO; i++) {  // calc_snow_tk, calc_snow_heat_capacity
-    if (i < top) {
-      thk[i] = 0.0;
-      cv[i] = 0.0;
-    } else {
-      const double bw = (ice[i] + liq[i]) / (frac_sno * dzl[i]);
-      thk[i] = ST_TKAIR + (7.75e-5 * bw + 1.105e-6 * bw * bw) * (ST_TKICE - ST_TKAIR);
-      if (frac_sno > 0.0) {
-        cv[i] = dmax(ST_THIN_SFCLAYER, (ST_CPWAT * liq[i] + ST_CPICE * ice[i]) / frac_sno);
-      } else {
-        cv[i] = ST_THIN_SFCLAYER;
-      }
-    }
-  }
-  (void)ltype;
-  double tk[NLEVTOT];  // calc_face_tk: tk[i] is the interface between cells i and i+1
-#pragma unroll
-  for (int i = 0; i < NLEVTOT - 1; i++) {
-    if (i < top) {
-      tk[i] = 0.0;
-    } else {
-      const double zi1 = LV(zisoi, i + 1);
-      tk[i] = thk[i] * thk[i + 1] * (z[i + 1] - z[i]) / (thk[i] * (z[i + 1] - zi1) + thk[i + 1] * (zi1 - z[i]));
-    }
-  }
-  tk[NLEVTOT - 1] = 0.0;
-  double tk_h2osfc, c_h2osfc, dz_h2osfc;
-  {
-    const double zh2osfc = 1.0e-3 * (0.5 * h2osfc0);
-    tk_h2osfc = ST_TKWAT * thk[NLEVSNO] * (z[NLEVSNO] + zh2osfc) / (ST_TKWAT * z[NLEVSNO] + thk[NLEVSNO] * zh2osfc);
-    if ((h2osfc0 > ST_THIN_SFCLAYER) && (frac_h2osfc > ST_THIN_SFCLAYER)) {
-      c_h2osfc = dmax(ST_THIN_SFCLAYER, ST_CPWAT * h2osfc0 / frac_h2osfc);
-      dz_h2osfc = dmax(ST_THIN_SFCLAYER, 1.0e-3 * h2osfc0 / frac_h2osfc);
-    } else {
-      c_h2osfc = ST_THIN_SFCLAYER;
-      dz_h2osfc = ST_THIN_SFCLAYER;
-    }
-  }
+  const double onemcn = 1.0 - ST_CNFAC;
 
   // ---- surface_heat_fluxes (:121-142)
   double t_h2osfc = S->t_h2osfc[c];
@@ -139,172 +164,177 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
     const int fvn = S->frac_veg_nosno[c];
     const double dlrad = S->dlrad[c], emg = S->emg[c], forc_lwrad = S->forc_lwrad[c], htvp = S->htvp[c];
     const double sabg_soil = S->sabg_soil[c];
+    const double t_soi0 = LV(t_soisno, NLEVSNO);
     S->sabg_chk[c] = frac_sno_eff * S->sabg_snow[c] + (1.0 - frac_sno_eff) * sabg_soil;
-    hs_soil = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, sabg_soil, t[NLEVSNO], S->eflx_sh_soil[c],
+    hs_soil = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, sabg_soil, t_soi0, S->eflx_sh_soil[c],
                                    S->qflx_ev_soil[c]);
     hs_h2osfc = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, sabg_soil, t_h2osfc, S->eflx_sh_h2osfc[c],
                                      S->qflx_ev_h2osfc[c]);
-    double t_top = t[NLEVSNO];  // snotop == nlevsno when there is no snow
-#pragma unroll
-    for (int i = 0; i < NLEVSNO; i++)
-      if (i == top) t_top = t[i];
-    hs_top_snow = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, LV(sabg_lyr, top), t_top, S->eflx_sh_snow[c],
-                                       S->qflx_ev_snow[c]);
+    hs_top_snow = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, LV(sabg_lyr, top), LV(t_soisno, top),
+                                       S->eflx_sh_snow[c], S->qflx_ev_snow[c]);
     dhsdT = -S->cgrnd[c] - 4.0 * emg * STEBOL * pow(S->t_grnd[c], 3.0);
   }
-
-  // ---- diffusive_heat_flux (:153-170): fn, fact
-  double fn[NLEVTOT], fact[NLEVTOT];
-#pragma unroll
-  for (int i = 0; i < NLEVTOT - 1; i++) {
-    fn[i] = (i < top) ? 0.0 : tk[i] * (t[i + 1] - t[i]) / (z[i + 1] - z[i]);
+  // heat capacity and height of standing surface water (soil_thermal_properties_impl.hh:255-279)
+  double c_h2osfc, dz_h2osfc;
+  if ((h2osfc0 > ST_THIN_SFCLAYER) && (frac_h2osfc > ST_THIN_SFCLAYER)) {
+    c_h2osfc = dmax(ST_THIN_SFCLAYER, ST_CPWAT * h2osfc0 / frac_h2osfc);
+    dz_h2osfc = dmax(ST_THIN_SFCLAYER, 1.0e-3 * h2osfc0 / frac_h2osfc);
+  } else {
+    c_h2osfc = ST_THIN_SFCLAYER;
+    dz_h2osfc = ST_THIN_SFCLAYER;
   }
-  fn[NLEVTOT - 1] = 0.0;
-#pragma unroll
+
+  // ---- one pass down the column: thermal properties, matrix factor, diffusive fluxes, the row of the system
+  //      (rows 0..4 snow, row 5 standing surface water, rows 6..20 soil; band 0 = 2nd superdiagonal, 1 = 1st
+  //      superdiagonal, 2 = diagonal, 3 = 1st subdiagonal, 4 = 2nd subdiagonal) and the forward sweep.  Only the
+  //      sweep's A, B, Z stay in registers; level quantities live in a sliding window (previous, current, next).
+  StSweep w;
+  w.A = S->st_work + c;
+  w.B = S->st_work + (int64_t)NROW * ld + c;
+  w.Z = S->st_work + (int64_t)2 * NROW * ld + c;
+  w.Am2 = w.Am1 = w.Bm2 = w.Bm1 = w.Zm2 = w.Zm1 = 0.0;
+  w.Y1 = w.U1 = w.r19 = w.l4_19 = w.A19 = 0.0;
+  double fact_sl1 = 0.0;  // matrix factor of the snow layer next to the ground (for phase_change_h2osfc)
+  double thk_cur, cv_cur;
+  st_level_props(S, c, ld, 0, top, snl, frac_sno, h2osno0, thk_cur, cv_cur);
+  double z_cur = LV(zsoi, 0), t_cur = LV(t_soisno, 0);
+  double z_prev = 0.0, tk_prev = 0.0, fn_prev = 0.0;
+#pragma unroll 1
   for (int i = 0; i < NLEVTOT; i++) {
+    double thk_nxt = 0.0, cv_nxt = 0.0, z_nxt = 0.0, t_nxt = 0.0;
+    if (i + 1 < NLEVTOT) {
+      st_level_props(S, c, ld, i + 1, top, snl, frac_sno, h2osno0, thk_nxt, cv_nxt);
+      z_nxt = LV(zsoi, i + 1);
+      t_nxt = LV(t_soisno, i + 1);
+    }
+    // calc_face_tk (:132), calc_diffusive_heat_flux (soil_temperature_impl.hh:45): interface i | i+1
+    double tk_i = 0.0, fn_i = 0.0;
+    if (i < NLEVTOT - 1 && i >= top) {
+      const double zi1 = LV(zisoi, i + 1);
+      tk_i = thk_cur * thk_nxt * (z_nxt - z_cur) / (thk_cur * (z_nxt - zi1) + thk_nxt * (zi1 - z_cur));
+      fn_i = tk_i * (t_nxt - t_cur) / (z_nxt - z_cur);
+    }
+    // calc_heat_flux_matrix_factor (:93)
+    double fact_i;
     if (i < top) {
-      fact[i] = 0.0;
-    } else if (i == top) {  // top active layer (i <= nlevsno, so z[i + 1] exists)
+      fact_i = 0.0;
+    } else if (i == top) {
       const double zit = LV(zisoi, i);
-      fact[i] = dtime / cv[i] * dzl[i] / (0.5 * (z[i] - zit + ST_CAPR * (z[i + 1] - zit)));
+      fact_i = dtime / cv_cur * LV(dz, i) / (0.5 * (z_cur - zit + ST_CAPR * (z_nxt - zit)));
     } else {
-      fact[i] = dtime / cv[i];
+      fact_i = dtime / cv_cur;
     }
-    LV(fact, i) = fact[i];
+    LV(fact, i) = fact_i;
+    if (i == NLEVSNO - 1) fact_sl1 = fact_i;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0, rr = 0.0;
+    if (i < NLEVSNO) {  // snow rows: get_rhs_snow, get_matrix_snow, get_matrix_snow_soil
+      if (i < top) {
+        l2 = 1.0;  // identity row
+      } else if (i == top) {
+        const double dzp = z_nxt - z_cur;
+        rr = t_cur + fact_i * (hs_top_snow - dhsdT * t_cur + ST_CNFAC * fn_i);
+        l2 = 1.0 + onemcn * fact_i * tk_i / dzp - fact_i * dhsdT;
+        if (snl > 1) l1 = -onemcn * fact_i * tk_i / dzp;
+      } else {
+        const double dzm = z_cur - z_prev;
+        const double dzp = z_nxt - z_cur;
+        rr = t_cur + ST_CNFAC * fact_i * (fn_i - fn_prev) + fact_i * LV(sabg_lyr, i);
+        l3 = -onemcn * fact_i * tk_prev / dzm;
+        l2 = 1.0 + onemcn * fact_i * (tk_i / dzp + tk_prev / dzm);
+        if (i != NLEVSNO - 1) l1 = -onemcn * fact_i * tk_i / dzp;
+      }
+      if (i == NLEVSNO - 1 && snl > 0) l0 = -onemcn * fact_i * tk_i / (z_nxt - z_cur);
+      st_push_row(w, ld, i, l0, l1, l2, l3, l4, rr);
+    } else {
+      double tk_h2osfc = 0.0;
+      if (i == NLEVSNO) {  // calc_h2osfc_tk (:238); the standing-surface-water row: get_rhs_ssw, get_matrix_ssw(_soil)
+        const double zh2osfc = 1.0e-3 * (0.5 * h2osfc0);
+        tk_h2osfc = ST_TKWAT * thk_cur * (z_cur + zh2osfc) / (ST_TKWAT * z_cur + thk_cur * zh2osfc);
+        const double dzw = 0.5 * dz_h2osfc + z_cur;
+        const double fn_h2osfc = tk_h2osfc * (t_cur - t_h2osfc) / dzw;
+        const double rw = t_h2osfc + (dtime / c_h2osfc) * (hs_h2osfc - dhsdT * t_h2osfc + ST_CNFAC * fn_h2osfc);
+        const double w2 = 1.0 + onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw - (dtime / c_h2osfc) * dhsdT;
+        const double w1 = -onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw;
+        st_push_row(w, ld, NLEVSNO, 0.0, w1, w2, 0.0, 0.0, rw);
+      }
+      // soil rows: get_rhs_soil, get_matrix_soil, get_matrix_soil_snow, get_matrix_soil_ssw
+      if (i == NLEVSNO) {
+        const double dzp = z_nxt - z_cur;
+        if (snl == 0) {
+          rr = t_cur + fact_i * (hs_top_snow - dhsdT * t_cur + ST_CNFAC * fn_i);
+          l2 = 1.0 + onemcn * fact_i * tk_i / dzp - fact_i * dhsdT;
+          l1 = -onemcn * fact_i * tk_i / dzp;
+        } else {
+          const double dzm = z_cur - z_prev;
+          rr = t_cur + fact_i * ((1.0 - frac_sno_eff) * (hs_soil - dhsdT * t_cur) + ST_CNFAC * (fn_i - frac_sno_eff * fn_prev));
+          rr += frac_sno_eff * fact_i * LV(sabg_lyr, NLEVSNO);
+          l2 = 1.0 + onemcn * fact_i * (tk_i / dzp + frac_sno_eff * tk_prev / dzm) - (1.0 - frac_sno_eff) * fact_i * dhsdT;
+          l1 = -onemcn * fact_i * tk_i / dzp;
+          l4 = -frac_sno_eff * onemcn * fact_i * tk_prev / dzm;
+        }
+        if (frac_h2osfc != 0.0) {
+          const double dzm = 0.5 * dz_h2osfc + z_cur;
+          l2 += frac_h2osfc * (onemcn * fact_i * tk_h2osfc / dzm + fact_i * dhsdT);
+          l3 = -frac_h2osfc * onemcn * fact_i * tk_h2osfc / (0.5 * dz_h2osfc + z_cur);
+        }
+      } else if (i < NLEVTOT - 1) {
+        const double dzm = z_cur - z_prev;
+        const double dzp = z_nxt - z_cur;
+        rr = t_cur + ST_CNFAC * fact_i * (fn_i - fn_prev);
+        l3 = -onemcn * fact_i * tk_prev / dzm;
+        l2 = 1.0 + onemcn * fact_i * (tk_i / dzp + tk_prev / dzm);
+        l1 = -onemcn * fact_i * tk_i / dzp;
+      } else {
+        const double dzm = z_cur - z_prev;
+        rr = t_cur - ST_CNFAC * fact_i * fn_prev + fact_i * fn_i;
+        l3 = -onemcn * fact_i * tk_prev / dzm;
+        l2 = 1.0 + onemcn * fact_i * tk_prev / dzm;
+      }
+      st_push_row(w, ld, i + 1, l0, l1, l2, l3, l4, rr);
+    }
+    z_prev = z_cur;
+    z_cur = z_nxt;
+    t_cur = t_nxt;
+    tk_prev = tk_i;
+    fn_prev = fn_i;
+    thk_cur = thk_nxt;
+    cv_cur = cv_nxt;
   }
 
-  // ---- set_RHS / set_LHS: rows 0..4 snow, row 5 standing surface water, rows 6..20 soil; band 0 = 2nd superdiagonal,
-  //      1 = 1st superdiagonal, 2 = diagonal, 3 = 1st subdiagonal, 4 = 2nd subdiagonal.  Rows above the snow pack
-  //      become identity rows for the sweep (the reference never visits them).
-  double L0[NROW], L1[NROW], L2[NROW], L3[NROW], L4[NROW], R[NROW];
-#pragma unroll
-  for (int i = 0; i < NROW; i++) {
-    L0[i] = L1[i] = L2[i] = L3[i] = L4[i] = 0.0;
-    R[i] = 0.0;
-  }
-  const double onemcn = 1.0 - ST_CNFAC;
-#pragma unroll
-  for (int i = 0; i < NLEVSNO; i++) {  // get_rhs_snow (:77-107), get_matrix_snow (:165-203), snow_soil (:206-227)
-    if (i == top) {
-      R[i] = t[i] + fact[i] * (hs_top_snow - dhsdT * t[i] + ST_CNFAC * fn[i]);
-      const double dzp = z[i + 1] - z[i];
-      L2[i] = 1.0 + onemcn * fact[i] * tk[i] / dzp - fact[i] * dhsdT;
-      if (snl > 1) L1[i] = -onemcn * fact[i] * tk[i] / dzp;
-    } else if (i > top) {
-      R[i] = t[i] + ST_CNFAC * fact[i] * (fn[i] - fn[i - 1]) + fact[i] * LV(sabg_lyr, i);
-      const double dzm = z[i] - z[i - 1];
-      const double dzp = z[i + 1] - z[i];
-      L3[i] = -onemcn * fact[i] * tk[i - 1] / dzm;
-      L2[i] = 1.0 + onemcn * fact[i] * (tk[i] / dzp + tk[i - 1] / dzm);
-      if (i != NLEVSNO - 1) L1[i] = -onemcn * fact[i] * tk[i] / dzp;
-    }
-  }
-  if (snl > 0) {
-    L0[NLEVSNO - 1] = -onemcn * fact[NLEVSNO - 1] * tk[NLEVSNO - 1] / (z[NLEVSNO] - z[NLEVSNO - 1]);
-  }
-  {  // standing surface water row: get_rhs_ssw (:111-133), get_matrix_ssw (:322-342), ssw_soil (:345-364)
-    const double dzw = 0.5 * dz_h2osfc + z[NLEVSNO];
-    const double fn_h2osfc = tk_h2osfc * (t[NLEVSNO] - t_h2osfc) / dzw;
-    R[NLEVSNO] = t_h2osfc + (dtime / c_h2osfc) * (hs_h2osfc - dhsdT * t_h2osfc + ST_CNFAC * fn_h2osfc);
-    L2[NLEVSNO] = 1.0 + onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw - (dtime / c_h2osfc) * dhsdT;
-    L1[NLEVSNO] = -onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw;
-  }
-  {  // soil rows: get_rhs_soil (:135-177), get_matrix_soil (:230-292), soil_snow (:295-319), soil_ssw (:367-390)
-    constexpr int s0 = NLEVSNO;   // level index of the top soil layer
-    constexpr int r0 = NLEVSNO + 1;  // its matrix row
-    const double dzp0 = z[s0 + 1] - z[s0];
-    if (snl == 0) {
-      R[r0] = t[s0] + fact[s0] * (hs_top_snow - dhsdT * t[s0] + ST_CNFAC * fn[s0]);
-      L2[r0] = 1.0 + onemcn * fact[s0] * tk[s0] / dzp0 - fact[s0] * dhsdT;
-      L1[r0] = -onemcn * fact[s0] * tk[s0] / dzp0;
-    } else {  // the snow / soil interface layer
-      const double dzm = z[s0] - z[s0 - 1];
-      R[r0] = t[s0] + fact[s0] * ((1.0 - frac_sno_eff) * (hs_soil - dhsdT * t[s0]) +
-                                  ST_CNFAC * (fn[s0] - frac_sno_eff * fn[s0 - 1]));
-      R[r0] += frac_sno_eff * fact[s0] * LV(sabg_lyr, s0);
-      L2[r0] = 1.0 + onemcn * fact[s0] * (tk[s0] / dzp0 + frac_sno_eff * tk[s0 - 1] / dzm) -
-               (1.0 - frac_sno_eff) * fact[s0] * dhsdT;
-      L1[r0] = -onemcn * fact[s0] * tk[s0] / dzp0;
-      L4[r0] = -frac_sno_eff * onemcn * fact[s0] * tk[s0 - 1] / dzm;
-    }
-#pragma unroll
-    for (int j = s0 + 1; j < NLEVTOT - 1; j++) {
-      const double dzm = z[j] - z[j - 1];
-      const double dzp = z[j + 1] - z[j];
-      R[j + 1] = t[j] + ST_CNFAC * fact[j] * (fn[j] - fn[j - 1]);
-      L3[j + 1] = -onemcn * fact[j] * tk[j - 1] / dzm;
-      L2[j + 1] = 1.0 + onemcn * fact[j] * (tk[j] / dzp + tk[j - 1] / dzm);
-      L1[j + 1] = -onemcn * fact[j] * tk[j] / dzp;
-    }
-    constexpr int bot = NLEVTOT - 1;
-    {
-      const double dzm = z[bot] - z[bot - 1];
-      R[bot + 1] = t[bot] - ST_CNFAC * fact[bot] * fn[bot - 1] + fact[bot] * fn[bot];
-      L3[bot + 1] = -onemcn * fact[bot] * tk[bot - 1] / dzm;
-      L2[bot + 1] = 1.0 + onemcn * fact[bot] * tk[bot - 1] / dzm;
-    }
-    if (frac_h2osfc != 0.0) {  // diagonal correction and coupling for standing surface water
-      const double dzm = 0.5 * dz_h2osfc + z[s0];
-      L2[r0] += frac_h2osfc * (onemcn * fact[s0] * tk_h2osfc / dzm + fact[s0] * dhsdT);
-      L3[r0] = -frac_h2osfc * onemcn * fact[s0] * tk_h2osfc / (0.5 * dz_h2osfc + z[s0]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NLEVSNO; i++) {
-    if (i < top) {  // identity row
-      L0[i] = L1[i] = L3[i] = L4[i] = 0.0;
-      L2[i] = 1.0;
-      R[i] = 0.0;
-    }
-  }
-
-  // ---- solver::PDMA (pentadiagonal_solver_impl.hh:16-76)
-  double A[NROW], B[NROW], Z[NROW];
+  // ---- back substitution (:69-74) and update_temperature (soil_temperature_impl.hh:154-177): row r holds level r for
+  //      the snow layers, standing surface water for r == 5, level r - 1 below; the new temperatures go to the state
+  //      as they appear, the phase-change pass reads them back
+  double t_soi0, t_ssw;
   {
-    double Am2 = 0.0, Am1 = 0.0, Bm2 = 0.0, Bm1 = 0.0, Zm2 = 0.0, Zm1 = 0.0;
-    constexpr int N = NROW;
-#pragma unroll
-    for (int i = 0; i < N - 2; i++) {
-      const double Y1 = L3[i] - Am2 * L4[i];
-      const double U1 = 1.0 / (L2[i] - Bm2 * L4[i] - Am1 * Y1);
-      A[i] = (L1[i] - Bm1 * Y1) * U1;
-      B[i] = L0[i] * U1;
-      Z[i] = (R[i] - Zm2 * L4[i] - Zm1 * Y1) * U1;
-      Am2 = Am1;
-      Am1 = A[i];
-      Bm2 = Bm1;
-      Bm1 = B[i];
-      Zm2 = Zm1;
-      Zm1 = Z[i];
+    double r2 = w.Zm1;                   // R(N-1) = Z(N-1)
+    double r1 = w.Zm2 - w.A19 * r2;      // R(N-2) = Z(N-2) - A(N-2) R(N-1)
+    LV(t_soisno, NLEVTOT - 1) = r2;
+    LV(t_soisno, NLEVTOT - 2) = r1;
+    t_soi0 = 0.0;
+    t_ssw = 0.0;
+#pragma unroll 1
+    for (int r = NROW - 3; r >= 0; --r) {
+      const double x = w.Z[(int64_t)r * ld] - w.A[(int64_t)r * ld] * r1 - w.B[(int64_t)r * ld] * r2;
+      r2 = r1;
+      r1 = x;
+      if (r > NLEVSNO) {
+        LV(t_soisno, r - 1) = x;
+        if (r == NLEVSNO + 1) t_soi0 = x;
+      } else if (r == NLEVSNO) {
+        t_ssw = x;
+      } else if (r >= top) {
+        LV(t_soisno, r) = x;
+      }
     }
-    // second row from the bottom and the bottom row, in the reference's own (slightly different) form (:55-66)
-    const double Y1 = L3[N - 2] - A[N - 4] * L4[N - 2];
-    const double U1 = 1.0 / (L2[N - 2] - B[N - 4] * L4[N - 2] - A[N - 3] * Y1);
-    A[N - 2] = (L1[N - 2] - B[N - 3] * Y1) * U1;
-    const double Y2 = L3[N - 1] - A[N - 3] * L4[N - 1];
-    const double U2 = 1.0 / (L2[N - 1] - B[N - 3] * L4[N - 1] - A[N - 2] * Y2);
-    Z[N - 2] = (R[N - 2] - Z[N - 3] * L4[N - 2] - Z[N - 3] * Y1) * U1;
-    Z[N - 1] = (R[N - 1] - Z[N - 2] * L4[N - 1] - Z[N - 2] * Y2) * U2;
-    R[N - 1] = Z[N - 1];
-    R[N - 2] = Z[N - 2] - A[N - 2] * R[N - 1];
-#pragma unroll
-    for (int i = N - 3; i >= 0; --i) R[i] = Z[i] - A[i] * R[i + 1] - B[i] * R[i + 2];
   }
+  t_h2osfc = (frac_h2osfc != 0.0) ? t_ssw : t_soi0;
+  double t_sl1 = LV(t_soisno, NLEVSNO - 1);  // the snow layer next to the ground (new value if active, else unchanged)
+  double ice_sl1 = LV(h2osoi_ice, NLEVSNO - 1);
 
-  // ---- update_temperature (soil_temperature_impl.hh:154-177)
-#pragma unroll
-  for (int i = 0; i < NLEVSNO; i++)
-    if (i >= top) t[i] = R[i];
-#pragma unroll
-  for (int i = NLEVSNO; i < NLEVTOT; i++) t[i] = R[i + 1];
-  t_h2osfc = (frac_h2osfc != 0.0) ? R[NLEVSNO] : t[NLEVSNO];
-
-  // ---- phase_change_h2osfc (phase_change_impl.hh:11-151); *_sl1 = the snow layer next to the ground (level 4)
+  // ---- phase_change_h2osfc (phase_change_impl.hh:11-151)
   double h2osfc = h2osfc0, h2osno = h2osno0, int_snow = S->int_snow[c], snow_depth = S->snow_depth[c];
   {
     double qflx_h2osfc_to_ice = 0.0, eflx_h2osfc_to_snow = 0.0, xmf_h2osfc = 0.0;
-    constexpr int sl1 = NLEVSNO - 1;
-    const double fact_sl1 = fact[sl1];
     if (frac_h2osfc > 0.0 && t_h2osfc <= TFRZ) {
       const double tinc = TFRZ - t_h2osfc;
       t_h2osfc = TFRZ;
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
       if (temp1 >= 0.0) {
         h2osno -= xm;
         int_snow -= xm;
-        if (snl > 0) ice[sl1] -= xm;
+        if (snl > 0) ice_sl1 -= xm;
         h2osfc += xm;
         xmf_h2osfc = hm;
         qflx_h2osfc_to_ice = -xm / dtime;
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
           snow_depth = h2osno / DENICE;
         }
         if (snl == 0) {
-          t[sl1] = t_h2osfc;
+          t_sl1 = t_h2osfc;
           eflx_h2osfc_to_snow = 0.0;
         } else {
           double c1, c2;
@@ -345,20 +375,20 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
           } else {
             c2 = 0.0;
           }
-          t[sl1] = (c1 * t[sl1] + c2 * t_h2osfc) / (c1 + c2);
-          eflx_h2osfc_to_snow = (t_h2osfc - t[sl1]) * c2 / dtime;
+          t_sl1 = (c1 * t_sl1 + c2 * t_h2osfc) / (c1 + c2);
+          eflx_h2osfc_to_snow = (t_h2osfc - t_sl1) * c2 / dtime;
         }
       } else {
         rho_avg = (h2osno * rho_avg + h2osfc * DENICE) / (h2osno + h2osfc);
         h2osno += h2osfc;
         int_snow += h2osfc;
         qflx_h2osfc_to_ice = h2osfc / dtime;
-        if (snl > 0) ice[sl1] = ice[sl1] + h2osfc;
+        if (snl > 0) ice_sl1 = ice_sl1 + h2osfc;
         t_h2osfc = t_h2osfc - temp1 * HFUS / (dtime * dhsdT - c_h2osfc);
         xmf_h2osfc = hm - frac_h2osfc * temp1 * HFUS / dtime;
         double c1, c2;
         if (snl == 0) {
-          t[sl1] = t_h2osfc;
+          t_sl1 = t_h2osfc;
         } else if (snl == 1) {
           c1 = frac_sno * (dtime / fact_sl1 - dhsdT * dtime);
           if (frac_h2osfc != 0.0) {
@@ -366,8 +396,8 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
           } else {
             c2 = 0.0;
           }
-          t[sl1] = (c1 * t[sl1] + c2 * t_h2osfc) / (c1 + c2);
-          t_h2osfc = t[sl1];
+          t_sl1 = (c1 * t_sl1 + c2 * t_h2osfc) / (c1 + c2);
+          t_h2osfc = t_sl1;
         } else {
           c1 = frac_sno / fact_sl1 * dtime;
           if (frac_h2osfc != 0.0) {
@@ -375,8 +405,8 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
           } else {
             c2 = 0.0;
           }
-          t[sl1] = (c1 * t[sl1] + c2 * t_h2osfc) / (c1 + c2);
-          t_h2osfc = t[sl1];
+          t_sl1 = (c1 * t_sl1 + c2 * t_h2osfc) / (c1 + c2);
+          t_h2osfc = t_sl1;
         }
         h2osfc = 0.0;
         if (frac_sno > 0.0 && snl > 0) {
@@ -391,206 +421,190 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
     S->eflx_h2osfc_snow[c] = eflx_h2osfc_to_snow;
   }
 
-  // ---- phase_change_soisno (phase_change_impl.hh:182-418)
-  {
-    double xmf = 0.0, qflx_snofrz = 0.0, qflx_snow_melt = 0.0, qflx_snomelt = 0.0;
-    double frz_lyr[NLEVSNO];
-    int imelt[NLEVTOT];
-    double tinc[NLEVTOT];
-#pragma unroll
-    for (int i = 0; i < NLEVSNO; i++) frz_lyr[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NLEVTOT; i++) {
-      imelt[i] = 0;  // (levels above the pack keep their stale flag in the state; their freezing rate is 0 either way)
-      tinc[i] = 0.0;
+  // ---- phase_change_soisno (phase_change_impl.hh:182-418).  The reference identifies melting / freezing layers in
+  //      two loops and then processes all layers; every step of a layer only reads that layer (and column scalars
+  //      that level 5 alone modifies after its own identification), so the three loops are fused level by level.
+  double xmf = 0.0, qflx_snofrz = 0.0, qflx_snow_melt = 0.0, qflx_snomelt = 0.0;
+  double t_top_new = 0.0;  // temperature of the top active layer after phase change (for update_t_grnd)
+  // level 4 as phase_change_h2osfc left it (it writes that level even when there is no snow layer)
+  LV(t_soisno, NLEVSNO - 1) = t_sl1;
+  LV(h2osoi_ice, NLEVSNO - 1) = ice_sl1;
+#pragma unroll 1
+  for (int i = 0; i < NLEVTOT; i++) {
+    if (i < top) {
+      if (i < NLEVSNO) LV(qflx_snofrz_lyr, i) = 0.0;
+      continue;
     }
-#pragma unroll
-    for (int i = 0; i < NLEVSNO; i++) {  // snow layers (:222-238)
-      if (i >= top) {
-        if (ice[i] > 0.0 && t[i] > TFRZ) {
-          imelt[i] = 1;
-          tinc[i] = TFRZ - t[i];
-          t[i] = TFRZ;
-        }
-        if (liq[i] > 0.0 && t[i] < TFRZ) {
-          imelt[i] = 2;
-          tinc[i] = TFRZ - t[i];
-          t[i] = TFRZ;
-        }
+    double t = LV(t_soisno, i);
+    double ice = LV(h2osoi_ice, i), liq = LV(h2osoi_liq, i);
+    const double fact_i = LV(fact, i);
+    int imelt = 0;
+    double tinc = 0.0, supercool = 0.0;
+    if (i < NLEVSNO) {  // snow (:222-238)
+      if (ice > 0.0 && t > TFRZ) {
+        imelt = 1;
+        tinc = TFRZ - t;
+        t = TFRZ;
       }
-    }
-    double supercool[NLEVGRND];
-#pragma unroll
-    for (int i = NLEVSNO; i < NLEVTOT; i++) {  // soil layers (:241-273)
-      if (ice[i] > 0.0 && t[i] > TFRZ) {
-        imelt[i] = 1;
-        tinc[i] = TFRZ - t[i];
-        t[i] = TFRZ;
+      if (liq > 0.0 && t < TFRZ) {
+        imelt = 2;
+        tinc = TFRZ - t;
+        t = TFRZ;
       }
-      supercool[i - NLEVSNO] = 0.0;
-      // ltype == istsoil for every column (the wrapper's dummy ltype): Zhao (1997) / Koren (1999) supercooled water
-      if (t[i] < TFRZ) {
-        const double smp = HFUS * (TFRZ - t[i]) / (GRAV * t[i]) * 1000.0;
-        supercool[i - NLEVSNO] = LV(watsat, i - NLEVSNO) * pow(smp / LV(sucsat, i - NLEVSNO), -1.0 / LV(bsw, i - NLEVSNO));
-        supercool[i - NLEVSNO] *= dzl[i] * 1000.0;
+    } else {  // soil (:241-273); ltype == istsoil: Zhao (1997) / Koren (1999) supercooled water
+      if (ice > 0.0 && t > TFRZ) {
+        imelt = 1;
+        tinc = TFRZ - t;
+        t = TFRZ;
       }
-      if (liq[i] > supercool[i - NLEVSNO] && t[i] < TFRZ) {
-        imelt[i] = 2;
-        tinc[i] = TFRZ - t[i];
-        t[i] = TFRZ;
+      if (t < TFRZ) {
+        const double smp = HFUS * (TFRZ - t) / (GRAV * t) * 1000.0;
+        const int j = i - NLEVSNO;
+        supercool = LV(watsat, j) * pow(smp / LV(sucsat, j), -1.0 / LV(bsw, j));
+        supercool *= LV(dz, i) * 1000.0;
+      }
+      if (liq > supercool && t < TFRZ) {
+        imelt = 2;
+        tinc = TFRZ - t;
+        t = TFRZ;
       }
       if (snl == 0 && h2osno > 0.0 && i == NLEVSNO) {
-        if (t[i] > TFRZ) {
-          imelt[i] = 1;
-          tinc[i] = TFRZ - t[i];
-          t[i] = TFRZ;
+        if (t > TFRZ) {
+          imelt = 1;
+          tinc = TFRZ - t;
+          t = TFRZ;
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < NLEVTOT; i++) {  // all active layers (:277-409)
-      if (i < top) continue;
-      double hm = 0.0;
-      if (imelt[i] > 0) {
-        if (i == top) {
-          if (i < NLEVSNO) {
-            hm = frac_sno_eff * (dhsdT * tinc[i] - tinc[i] / fact[i]);
+    // energy surplus / deficit and the rate of melting / freezing (:277-409)
+    double hm = 0.0;
+    if (imelt > 0) {
+      if (i == top) {
+        if (i < NLEVSNO) {
+          hm = frac_sno_eff * (dhsdT * tinc - tinc / fact_i);
+        } else {
+          const double temp_hm = dhsdT * tinc - tinc / fact_i;
+          hm = (frac_h2osfc != 0.0) ? temp_hm - frac_h2osfc * (dhsdT * tinc) : temp_hm;
+        }
+      } else if (i == NLEVSNO) {
+        hm = (1.0 - frac_sno_eff - frac_h2osfc) * dhsdT * tinc - tinc / fact_i;
+      } else {
+        if (i < NLEVSNO) {
+          hm = -frac_sno_eff * (tinc / fact_i);
+        } else {
+          hm = -tinc / fact_i;
+        }
+      }
+    }
+    if (imelt == 1 && hm < 0.0) {
+      hm = 0.0;
+      imelt = 0;
+    }
+    if (imelt == 2 && hm > 0.0) {
+      hm = 0.0;
+      imelt = 0;
+    }
+    double frz = 0.0;
+    if (imelt > 0 && fabs(hm) > 0.0) {
+      double xm = hm * dtime / HFUS;
+      if (i == NLEVSNO) {
+        if (snl == 0 && h2osno > 0.0 && xm > 0.0) {
+          const double temp1 = h2osno;
+          h2osno = dmax(0.0, temp1 - xm);
+          const double propor = h2osno / temp1;
+          snow_depth *= propor;
+          const double heatr = hm - HFUS * (temp1 - h2osno) / dtime;
+          if (heatr > 0.0) {
+            xm = heatr * dtime / HFUS;
+            hm = heatr;
           } else {
-            const double temp_hm = dhsdT * tinc[i] - tinc[i] / fact[i];
-            hm = (frac_h2osfc != 0.0) ? temp_hm - frac_h2osfc * (dhsdT * tinc[i]) : temp_hm;
+            xm = 0.0;
+            hm = 0.0;
+          }
+          qflx_snomelt = dmax(0.0, temp1 - h2osno) / dtime;
+          xmf = HFUS * qflx_snomelt;
+          qflx_snow_melt = qflx_snomelt;
+        }
+      }
+      double heatr = 0.0;
+      const double wmass0 = ice + liq;
+      const double wice0 = ice;
+      if (xm > 0.0) {
+        ice = dmax(0.0, wice0 - xm);
+        heatr = hm - HFUS * (wice0 - ice) / dtime;
+      } else if (xm < 0.0) {
+        if (i < NLEVSNO) {
+          ice = dmin(wmass0, wice0 - xm);
+        } else {
+          if (wmass0 < supercool) {
+            ice = 0.0;
+          } else {
+            ice = dmin(wmass0 - supercool, wice0 - xm);
+          }
+        }
+        heatr = hm - HFUS * (wice0 - ice) / dtime;
+      }
+      liq = dmax(0.0, wmass0 - ice);
+      if (fabs(heatr) > 0.0) {
+        if (i == top) {
+          if (snl == 0) {
+            t += fact_i * heatr / (1.0 - (1.0 - frac_h2osfc) * fact_i * dhsdT);
+          } else {
+            t += (fact_i / frac_sno_eff) * heatr / (1.0 - fact_i * dhsdT);
           }
         } else if (i == NLEVSNO) {
-          hm = (1.0 - frac_sno_eff - frac_h2osfc) * dhsdT * tinc[i] - tinc[i] / fact[i];
+          t += fact_i * heatr / (1.0 - (1.0 - frac_sno_eff - frac_h2osfc) * fact_i * dhsdT);
         } else {
-          if (i < NLEVSNO) {
-            hm = -frac_sno_eff * (tinc[i] / fact[i]);
+          if (i >= NLEVSNO) {
+            t += fact_i * heatr;
           } else {
-            hm = -tinc[i] / fact[i];
+            if (frac_sno_eff > 0.0) t += (fact_i / frac_sno_eff) * heatr;
           }
         }
-      }
-      if (imelt[i] == 1 && hm < 0.0) {
-        hm = 0.0;
-        imelt[i] = 0;
-      }
-      if (imelt[i] == 2 && hm > 0.0) {
-        hm = 0.0;
-        imelt[i] = 0;
-      }
-      if (imelt[i] > 0 && fabs(hm) > 0.0) {
-        double xm = hm * dtime / HFUS;
-        if (i == NLEVSNO) {
-          if (snl == 0 && h2osno > 0.0 && xm > 0.0) {
-            const double temp1 = h2osno;
-            h2osno = dmax(0.0, temp1 - xm);
-            const double propor = h2osno / temp1;
-            snow_depth *= propor;
-            const double heatr = hm - HFUS * (temp1 - h2osno) / dtime;
-            if (heatr > 0.0) {
-              xm = heatr * dtime / HFUS;
-              hm = heatr;
-            } else {
-              xm = 0.0;
-              hm = 0.0;
-            }
-            qflx_snomelt = dmax(0.0, temp1 - h2osno) / dtime;
-            xmf = HFUS * qflx_snomelt;
-            qflx_snow_melt = qflx_snomelt;
-          }
+        if (i < NLEVSNO) {
+          if (liq * ice > 0.0) t = TFRZ;
         }
-        double heatr = 0.0;
-        const double wmass0 = ice[i] + liq[i];
-        const double wice0 = ice[i];
-        if (xm > 0.0) {
-          ice[i] = dmax(0.0, wice0 - xm);
-          heatr = hm - HFUS * (wice0 - ice[i]) / dtime;
-        } else if (xm < 0.0) {
-          if (i < NLEVSNO) {
-            ice[i] = dmin(wmass0, wice0 - xm);
-          } else {
-            const double sc = supercool[i >= NLEVSNO ? i - NLEVSNO : 0];
-            if (wmass0 < sc) {
-              ice[i] = 0.0;
-            } else {
-              ice[i] = dmin(wmass0 - sc, wice0 - xm);
-            }
-          }
-          heatr = hm - HFUS * (wice0 - ice[i]) / dtime;
-        }
-        liq[i] = dmax(0.0, wmass0 - ice[i]);
-        if (fabs(heatr) > 0.0) {
-          if (i == top) {
-            if (snl == 0) {
-              t[i] += fact[i] * heatr / (1.0 - (1.0 - frac_h2osfc) * fact[i] * dhsdT);
-            } else {
-              t[i] += (fact[i] / frac_sno_eff) * heatr / (1.0 - fact[i] * dhsdT);
-            }
-          } else if (i == NLEVSNO) {
-            t[i] += fact[i] * heatr / (1.0 - (1.0 - frac_sno_eff - frac_h2osfc) * fact[i] * dhsdT);
-          } else {
-            if (i >= NLEVSNO) {
-              t[i] += fact[i] * heatr;
-            } else {
-              if (frac_sno_eff > 0.0) t[i] += (fact[i] / frac_sno_eff) * heatr;
-            }
-          }
-          if (i < NLEVSNO) {
-            if (liq[i] * ice[i] > 0.0) t[i] = TFRZ;
-          }
-        }
-        xmf += HFUS * (wice0 - ice[i]) / dtime;
-        if (imelt[i] == 1 && i < NLEVSNO) qflx_snomelt += dmax(0.0, (wice0 - ice[i])) / dtime;
-        if (imelt[i] == 2 && i < NLEVSNO) frz_lyr[i < NLEVSNO ? i : 0] = dmax(0.0, (ice[i] - wice0)) / dtime;
       }
+      xmf += HFUS * (wice0 - ice) / dtime;
+      if (imelt == 1 && i < NLEVSNO) qflx_snomelt += dmax(0.0, (wice0 - ice)) / dtime;
+      if (imelt == 2 && i < NLEVSNO) frz = dmax(0.0, (ice - wice0)) / dtime;
     }
-#pragma unroll
-    for (int i = 0; i < NLEVSNO; i++) {
-      if (imelt[i] == 2) qflx_snofrz += frz_lyr[i];
-      LV(qflx_snofrz_lyr, i) = frz_lyr[i];
+    if (i < NLEVSNO) {
+      LV(qflx_snofrz_lyr, i) = frz;
+      if (imelt == 2) qflx_snofrz += frz;
     }
-#pragma unroll
-    for (int i = 0; i < NLEVTOT; i++) {
-      if (i >= top) LV(imelt, i) = imelt[i];
-    }
-    S->xmf[c] = xmf;
-    S->qflx_snofrz[c] = qflx_snofrz;
-    S->qflx_snow_melt[c] = qflx_snow_melt;
-    S->qflx_snomelt[c] = qflx_snomelt;
-    S->eflx_snomelt[c] = qflx_snomelt * HFUS;
+    LV(imelt, i) = imelt;
+    LV(t_soisno, i) = t;
+    LV(h2osoi_ice, i) = ice;
+    LV(h2osoi_liq, i) = liq;
+    if (i == top) t_top_new = t;
+    if (i == NLEVSNO) t_soi0 = t;
   }
-
-  // ---- state writes and update_t_grnd (soil_temperature_impl.hh:179-205)
-#pragma unroll
-  for (int i = 0; i < NLEVTOT; i++) {
-    // levels above the snow pack are never written by the reference, except level 4 by phase_change_h2osfc
-    if (i >= top || i == NLEVSNO - 1) {
-      LV(t_soisno, i) = t[i];
-      LV(h2osoi_ice, i) = ice[i];
-    }
-    if (i >= top) LV(h2osoi_liq, i) = liq[i];
-  }
+  S->xmf[c] = xmf;
+  S->qflx_snofrz[c] = qflx_snofrz;
+  S->qflx_snow_melt[c] = qflx_snow_melt;
+  S->qflx_snomelt[c] = qflx_snomelt;
+  S->eflx_snomelt[c] = qflx_snomelt * HFUS;
   S->t_h2osfc[c] = t_h2osfc;
   S->h2osfc[c] = h2osfc;
   S->h2osno[c] = h2osno;
   S->int_snow[c] = int_snow;
   S->snow_depth[c] = snow_depth;
+
+  // ---- update_t_grnd (soil_temperature_impl.hh:179-205)
   {
-    double t_top = t[NLEVSNO];
-#pragma unroll
-    for (int i = 0; i < NLEVSNO; i++)
-      if (i == top) t_top = t[i];
     double t_grnd;
     if (snl > 0) {
       if (frac_h2osfc != 0.0) {
-        t_grnd = frac_sno_eff * t_top + (1.0 - frac_sno_eff - frac_h2osfc) * t[NLEVSNO] + frac_h2osfc * t_h2osfc;
+        t_grnd = frac_sno_eff * t_top_new + (1.0 - frac_sno_eff - frac_h2osfc) * t_soi0 + frac_h2osfc * t_h2osfc;
       } else {
-        t_grnd = frac_sno_eff * t_top + (1.0 - frac_sno_eff) * t[NLEVSNO];
+        t_grnd = frac_sno_eff * t_top_new + (1.0 - frac_sno_eff) * t_soi0;
       }
     } else {
       if (frac_h2osfc != 0.0) {
-        t_grnd = (1.0 - frac_h2osfc) * t[NLEVSNO] + frac_h2osfc * t_h2osfc;
+        t_grnd = (1.0 - frac_h2osfc) * t_soi0 + frac_h2osfc * t_h2osfc;
       } else {
-        t_grnd = t[NLEVSNO];
+        t_grnd = t_soi0;
       }
     }
     S->t_grnd[c] = t_grnd;

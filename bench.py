@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - gridcell-timesteps/sec of the full water+energy timestep (all 7 kernels) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--cols C] [--tier A|B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cols C] [--tier A|B] [--workload timestep7|soil_temperature]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU.  Columns shard halo-free across ranks (elmkernels_amd.decomp: the reference's 1-D block
@@ -62,7 +62,7 @@ def build_state(ncols, device, tier, seed):
     return D, (cols, scal, soil)
 
 
-def cpu_baseline(host_state, budget_s=15.0):
+def cpu_baseline(host_state, budget_s=15.0, workload="timestep7"):
     """The oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP) on the
     host cores, on a bounded sample of the same workload."""
     from tests import helpers as H
@@ -78,13 +78,20 @@ def cpu_baseline(host_state, budget_s=15.0):
     tveg = S["t_veg"].copy()
     hg = {k: S[k].copy() for k in RESTORE_FIELDS[1:]}
     S.timestep7(1800.0)  # warm-up (thread pool, page faults)
+    if workload == "soil_temperature":
+        saved = {k: S[k].copy() for k in SOIL_RESTORE}
     steps = 0
     t0 = time.perf_counter()
     while True:
-        S["t_veg"][:] = tveg
-        for k, v in hg.items():
-            S[k][:] = v
-        S.timestep7(1800.0)
+        if workload == "soil_temperature":
+            for k, v in saved.items():
+                S[k][...] = v
+            S.soil_temperature(1800.0)
+        else:
+            S["t_veg"][:] = tveg
+            for k, v in hg.items():
+                S[k][:] = v
+            S.timestep7(1800.0)
         steps += 1
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 5000:
@@ -109,10 +116,10 @@ SUB_KERNELS = {
 
 def pmc_traffic(wrapper, args):
     """HBM bytes per launch of the wrapper's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    calibrated on gfx950, WRITE_SIZE as is; profiles/r01_hbm_traffic_pmc.json).  The counters cannot be read from
-    inside this process, so the number is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
-    if args.cols != 1_000_000 or args.tier != "B" or not os.path.exists(path):
+    calibrated on gfx950, WRITE_SIZE as is; profiles/r01_hbm_traffic_pmc_tier{A,B}.json).  The counters cannot be read
+    from inside this process, so the number is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_pmc_tier{args.tier}.json")
+    if args.cols != 1_000_000 or not os.path.exists(path):
         return None
     k = json.load(open(path))["kernels"]
     try:
@@ -121,13 +128,70 @@ def pmc_traffic(wrapper, args):
         return None
 
 
+SOIL_ALGO_BYTES = 2860  # soil_temperature: 1972 B read + 888 B written per column (tally in DESIGN.md section 9)
+SOIL_RESTORE = ["t_soisno", "h2osoi_ice", "h2osoi_liq", "t_h2osfc", "h2osfc", "h2osno", "snow_depth", "int_snow", "t_grnd"]
+
+
+def timed_steps(D, workload, steps, warmup, sync_all, dist, torch):
+    """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks -> seconds."""
+    from elmkernels_amd import state as st
+
+    if workload == "timestep7":
+        def step():
+            D.restore_fields()
+            st.timestep7(D, 1800.0)
+    else:
+        def step():
+            D.restore_fields()
+            st.kokkos_soil_temperature(D, 1800.0)
+    for _ in range(warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    D.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def event_time_soil(D, nsteps):
+    """Mean device time of the soil_temperature kernel: HIP events are not exposed for it, so time the launches
+    back to back on the context's stream between two host synchronisations (restore excluded by subtraction)."""
+    from elmkernels_amd import state as st
+
+    D.sync()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        D.restore_fields()
+    D.sync()
+    t_restore = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        D.restore_fields()
+        st.kokkos_soil_temperature(D, 1800.0)
+    D.sync()
+    return max(1e-9, (time.perf_counter() - t0 - t_restore) / nsteps) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cols", type=int, default=1_000_000, help="columns per GPU (BASELINE config 2: 1M)")
-    ap.add_argument("--tier", default="B", choices=["A", "B"])
+    ap.add_argument("--tier", default="A", choices=["A", "B"],
+                    help="synthetic state (SURVEY.md 8(d)): A fixture-tiled (default), B branch-mix (snow layers, bare ground, C4 ...)")
+    ap.add_argument("--workload", default="timestep7", choices=["timestep7", "soil_temperature"],
+                    help="timestep7: BASELINE config 2 (the 7 wrappers); soil_temperature: config 3 (the soil-column vertical solve)")
+    ap.add_argument("--no-other-tier", action="store_true", help="skip the secondary measurement on the other tier")
     ap.add_argument("--seed", type=int, default=0x5EEDE1A0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the per-kernel HIP-event profile")
@@ -158,7 +222,17 @@ def main():
     # weak scaling: every rank owns args.cols columns; the global problem is the 1-D block split of world*cols
     ncols_global = args.cols * world
     start, ncols = decomp.block_range(ncols_global, world, rank)
-    D, host_state = build_state(ncols, local_rank, args.tier, args.seed + rank)
+    soil = args.workload == "soil_temperature"
+
+    def prepared(tier):
+        D, host_state = build_state(ncols, local_rank, tier, args.seed + rank)
+        if soil:  # the solve follows the seven wrappers: run them once, then keep the state the solve starts from
+            st.timestep7(D, 1800.0)
+            D.snapshot_fields(SOIL_RESTORE)
+            D.sync()
+        return D, host_state
+
+    D, host_state = prepared(args.tier)
 
     def sync_all():
         D.sync()
@@ -166,40 +240,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step():
-        D.restore_fields()
-        st.timestep7(D, 1800.0)
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    D.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(D, args.workload, args.steps, args.warmup, sync_all, dist, torch)
 
     # per-kernel device time, HIP events recorded on the stream the kernels are launched on
-    D.restore_fields()
-    ms, ms_total = D.profile_timestep7(1800.0, max(1, args.profile_steps))
+    if soil:
+        ms, ms_total = [], event_time_soil(D, max(1, args.profile_steps))
+    else:
+        D.restore_fields()
+        ms, ms_total = D.profile_timestep7(1800.0, max(1, args.profile_steps))
     flags, first_bad = D.error_summary()
+    state_gb = round(D.device_bytes / 1e9, 3)
+
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_tier:
+        D.close()
+        D = None
+        ot = "B" if args.tier == "A" else "A"
+        D2, _ = prepared(ot)
+
+        def sync2():
+            D2.sync()
+            torch.cuda.synchronize()
+
+        el2 = timed_steps(D2, args.workload, args.steps, args.warmup, sync2, None, torch)
+        other = {"tier": {"A": "fixture-tiled", "B": "branch-mix"}[ot], "value": ncols_global * args.steps / el2,
+                 "ms_per_step": el2 / args.steps * 1e3}
+        D2.close()
 
     if rank == 0:
         value = ncols_global * args.steps / elapsed
-        kern = {}
-        for name, m in zip(st.KERNEL_NAMES, ms):
-            gbs = ALGO_BYTES[name] * ncols / (m * 1e-3) / 1e9 if m > 0 else 0.0
-            kern[name] = {"ms": round(m, 4), "algo_GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(zip(st.KERNEL_NAMES, ms), key=lambda x: x[1])
-        dom_gbs = ALGO_BYTES[dom[0]] * ncols / (dom[1] * 1e-3) / 1e9
-        step_gbs = ALGO_BYTES_STEP * ncols / (ms_total * 1e-3) / 1e9
+        tier_name = {"A": "fixture-tiled", "B": "branch-mix"}[args.tier]
         out = {
             "metric": "gridcell-timesteps/sec",
             "value": value,
@@ -213,40 +283,53 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {
-                "workload": f"full water+energy timestep (7 kernels), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
-                "columns_per_gpu": args.cols,
-                "columns_total": ncols_global,
-                "levels": 20,
-                "tier": {"A": "fixture-tiled", "B": "branch-mix"}[args.tier],
+        }
+        if soil:
+            gbs = SOIL_ALGO_BYTES * ncols / (ms_total * 1e-3) / 1e9
+            out["config"] = {
+                "workload": f"soil-column vertical solve (kokkos_soil_temperature: 21-row pentadiagonal system, phase change), {args.cols} columns per GPU, fp64",
+                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name,
                 "parallelism": f"columns block-split over {world} GPU(s), no collective",
-            },
-            "roofline": {
+            }
+            out["roofline"] = {"bound": "hbm", "kernel": "k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_column": SOIL_ALGO_BYTES, "avg_launch_ms": ms_total}
+        else:
+            kern = {}
+            for name, m in zip(st.KERNEL_NAMES, ms):
+                gbs = ALGO_BYTES[name] * ncols / (m * 1e-3) / 1e9 if m > 0 else 0.0
+                kern[name] = {"ms": round(m, 4), "algo_GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            dom = max(zip(st.KERNEL_NAMES, ms), key=lambda x: x[1])
+            dom_gbs = ALGO_BYTES[dom[0]] * ncols / (dom[1] * 1e-3) / 1e9
+            step_gbs = ALGO_BYTES_STEP * ncols / (ms_total * 1e-3) / 1e9
+            out["config"] = {
+                "workload": f"full water+energy timestep (7 kernels), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
+                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name,
+                "parallelism": f"columns block-split over {world} GPU(s), no collective",
+            }
+            out["roofline"] = {
                 "bound": "hbm",
                 "kernel": " + ".join(n.replace("elmk::", "") for n in SUB_KERNELS[dom[0]]),
-                "achieved": dom_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": dom_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom[0], args),
-                "bytes_per_column": ALGO_BYTES[dom[0]],
-                "avg_launch_ms": dom[1],
-            },
-            "timestep_roofline": {
+                "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom[0], args), "bytes_per_column": ALGO_BYTES[dom[0]], "avg_launch_ms": dom[1],
+            }
+            out["timestep_roofline"] = {
                 "bytes_per_column_step": ALGO_BYTES_STEP, "achieved_GBps": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                 "ms_per_step_events": ms_total,
-            },
-            "kernels": kern,
-            "error_flags": flags,
-            "device_state_GB": round(D.device_bytes / 1e9, 3),
-        }
+            }
+            out["kernels"] = kern
+        out["error_flags"] = flags
+        out["device_state_GB"] = state_gb
+        if other is not None:
+            out["other_tier"] = other
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_state)
+            out["cpu_baseline"] = cpu_baseline(host_state, workload=args.workload)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    D.close()
+    if D is not None:
+        D.close()
 
 
 if __name__ == "__main__":

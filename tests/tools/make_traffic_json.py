@@ -23,9 +23,10 @@ def per_kernel(root, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 cols = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
+tier = sys.argv[5] if len(sys.argv) > 5 else "B"
 out = {
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), tests/tools/traffic_probe.py, "
-            f"{cols} columns tier B; values are per-launch means in KiB as reported. Calibration on elmk::k_copy (1 GiB read + "
+            f"{cols} columns tier {tier}; values are per-launch means in KiB as reported. Calibration on elmk::k_copy (1 GiB read + "
             "1 GiB written with the kernels' own 8-byte-per-lane access shape): FETCH_SIZE reads exactly 1/2 of the bytes, "
             "WRITE_SIZE reads them exactly (as MI355X_MICROARCH.md says for wide streams) -> "
             "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.",

@@ -14,6 +14,8 @@ from .state import (  # noqa: F401
     kokkos_bareground_fluxes,
     kokkos_canopy_fluxes,
     kokkos_soil_temperature,
+    kokkos_surface_fluxes,
+    kokkos_evaluate_conservation,
     kokkos_canopy_hydrology,
     kokkos_canopy_temperature,
     kokkos_frac_wet,

@@ -182,7 +182,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
   const size_t stw_bytes = align_up((size_t)63 * (size_t)ctx->ld * 8, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes + stw_bytes;
+  const size_t cons_bytes = align_up((size_t)8 * (size_t)ctx->ld * 8 + (size_t)8 * ELMK_CONS_NPART * 3 * 8 + 8 * 3 * 8, 256);
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes + stw_bytes + cons_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -224,6 +225,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     h.alb_snow = (double*)q;
     q += snow_bytes;
     h.st_work = (double*)q;
+    q += stw_bytes;
+    h.cons_diag = (double*)q;
     h.cf_nblk = cf_nblk;
   }
   {
@@ -568,6 +571,33 @@ int elmk_soil_temperature(elmk_ctx* ctx, double dt)
   PHYSICS_PROLOGUE();
   launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
   HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_surface_fluxes(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_evaluate_conservation(elmk_ctx* ctx, double dt, double* min_max_sum, double* per_column)
+{
+  PHYSICS_PROLOGUE();
+  if (!min_max_sum) return invalid(ctx, "elmk_evaluate_conservation: min_max_sum is NULL");
+  double* diag = ctx->h.cons_diag;
+  double* part = diag + (size_t)8 * ctx->ld;
+  double* out = part + (size_t)8 * ELMK_CONS_NPART * 3;
+  launch_conservation(ctx->d, ctx->ncols, ctx->ld, dt, diag, part, out, ctx->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(min_max_sum, out, 8 * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (per_column) {  // [8][ncols], diagnostic-major
+    for (int k = 0; k < 8; k++)
+      HIPCHK(hipMemcpyAsync(per_column + (size_t)k * ctx->ncols, diag + (size_t)k * ctx->ld, (size_t)ctx->ncols * 8,
+                            hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return ELMK_OK;
 }
 

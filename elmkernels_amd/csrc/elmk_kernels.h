@@ -29,6 +29,11 @@ void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
 // next row after the seven: soil / snow column temperature
 void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st);
+// surface fluxes after the solve, conservation diagnostics reduced to (min, max, sum)
+constexpr int ELMK_CONS_NPART = 512;  // stage-1 partials per diagnostic
+void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+void launch_conservation(const DevState* S, int64_t n, int64_t ld, double dt, const double* diag, double* part, double* out,
+                         hipStream_t st);
 
 // layout conversion between the reference's [column][level] host layout and device SoA [level][column]
 // staging: dense buffer of n*nlev elements in device memory; elem = element size in bytes (1, 4 or 8)

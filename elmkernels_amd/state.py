@@ -256,6 +256,24 @@ def kokkos_soil_temperature(S, dt):
     S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")
 
 
+def kokkos_surface_fluxes(S, dt):
+    """surface_fluxes_kokkos.cc:5-107 (follows soil_temperature in ELMInterface::advance)."""
+    S._chk(S.lib.elmk_surface_fluxes(S.ctx, float(dt)), "surface_fluxes")
+
+
+CONSERVATION_NAMES = ("dtend_column_h2o", "errh2o", "errh2osno", "dwb", "errsol", "errlon", "errseb", "netrad")
+
+
+def kokkos_evaluate_conservation(S, dt, per_column=False):
+    """conserved_quantity_kokkos.cc:8-81 -> min_max_sum [8, 3] (rows: CONSERVATION_NAMES) and, if asked, the
+    per-column values [ncols, 8]."""
+    mms = np.zeros((8, 3))
+    cols = np.zeros((8, S.ncols)) if per_column else None
+    S._chk(S.lib.elmk_evaluate_conservation(S.ctx, float(dt), mms.ctypes.data_as(C.c_void_p),
+                                            cols.ctypes.data_as(C.c_void_p) if per_column else None), "evaluate_conservation")
+    return (mms, np.ascontiguousarray(cols.T)) if per_column else mms
+
+
 def timestep7(S, dt):
     """The seven calls of ELMInterface::advance (driver/kokkos/elm_kokkos_interface.cc:289-307), in order."""
     S._chk(S.lib.elmk_timestep7(S.ctx, float(dt)), "timestep7")

@@ -230,4 +230,8 @@ def make_state(field_table, n, tier="A", seed=0x5EEDE1A0, perturb=True):
         sat, dry = soil_color_tables()
         soil = dict(albsat=sat, albdry=dry)
     cols = tile(base, n, seed=seed, perturb=perturb) if n != next(iter(base.values())).shape[0] else base
+    if "dtbegin_column_h2o" in cols:  # what the driver records at the start of a step (conservation diagnostics)
+        cols["dtbegin_column_h2o"] = (cols["h2ocan"] + cols["h2osno"] + cols["h2osfc"]
+                                      + (cols["h2osoi_ice"] + cols["h2osoi_liq"]).sum(axis=1))
+        cols["h2osno_old"] = cols["h2osno"].copy()
     return cols, scal, soil

@@ -27,6 +27,8 @@
  *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
  *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7
  *   kokkos_soil_temperature(S,dt)   soil_temperature_kokkos.hh        elmk_soil_temperature
+ *   kokkos_surface_fluxes(S,dt)     surface_fluxes_kokkos.hh          elmk_surface_fluxes
+ *   kokkos_evaluate_conservation    conserved_quantity_kokkos.hh      elmk_evaluate_conservation
  *   throw / assert inside physics   (list: SURVEY.md section 5)       per-column flag word, elmk_error_summary
  *
  * Conventions
@@ -186,6 +188,15 @@ int elmk_timestep7(elmk_ctx *ctx, double dt);
  * soil_temperature_kokkos.cc:6-278 - thermal properties, the 21-row pentadiagonal temperature system of
  * snow / standing surface water / soil, its solve, phase change, ground temperature */
 int elmk_soil_temperature(elmk_ctx *ctx, double dt);
+/* kokkos_surface_fluxes(S, dt) (surface_fluxes_kokkos.cc:5-107): flux corrections for the new ground temperature,
+ * ground heat flux, total fluxes, dew / sublimation partition, outgoing longwave, soil energy balance */
+int elmk_surface_fluxes(elmk_ctx *ctx, double dt);
+/* kokkos_evaluate_conservation(S, dt) (conserved_quantity_kokkos.cc:8-81).  The reference keeps its eight
+ * diagnostics in wrapper-local Views and prints column 0; here min_max_sum[8][3] receives (min, max, sum) over the
+ * context's columns of dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad - what a multi-GPU
+ * run all-reduces with MIN / MAX / SUM (the reference's min_max_sum, src/utils/min_max_sum.hh:57-66) - and
+ * per_column (may be NULL) the values themselves, [8][ncols].  Synchronises. */
+int elmk_evaluate_conservation(elmk_ctx *ctx, double dt, double *min_max_sum, double *per_column);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* OR of all columns' flag words and the first column with a fatal bit (-1 if none); synchronises */

@@ -144,7 +144,11 @@ typedef struct {
   /* soil_temperature (next row after the seven wrappers): elm_state.h:86,139-155 */                        \
   X(tkmg, D, 15) X(tkdry, D, 15) X(csol, D, 20) X(fact, D, 20) X(imelt, I, 20) X(xmf, D, 1)                  \
   X(xmf_h2osfc, D, 1) X(qflx_h2osfc_ice, D, 1) X(eflx_h2osfc_snow, D, 1) X(qflx_snofrz, D, 1)                \
-  X(qflx_snomelt, D, 1) X(eflx_snomelt, D, 1) X(qflx_snofrz_lyr, D, 5) X(sabg_chk, D, 1)
+  X(qflx_snomelt, D, 1) X(eflx_snomelt, D, 1) X(qflx_snofrz_lyr, D, 5) X(sabg_chk, D, 1)                      \
+  /* surface_fluxes + conservation diagnostics: elm_state.h / elm_state_impl.hh:146,297-345 */               \
+  X(eflx_soil_grnd, D, 1) X(eflx_lwrad_out, D, 1) X(eflx_lwrad_net, D, 1) X(qflx_evap_grnd, D, 1)            \
+  X(qflx_sub_snow, D, 1) X(qflx_dew_snow, D, 1) X(qflx_dew_grnd, D, 1) X(soil_e_balance, D, 1)               \
+  X(dtbegin_column_h2o, D, 1) X(h2osno_old, D, 1) X(qflx_sl_top_soil, D, 1)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -208,6 +212,11 @@ void elmo_soil_temperature(elmo_state *S, double dt);
    lhs [ncols][21][5], rhs [ncols][21] (right-hand side before the solve), sol [ncols][21], cv [ncols][20],
    hs [ncols][4] = {hs_soil, hs_h2osfc, hs_top_snow, dhsdT}; any pointer may be NULL */
 void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs, double *rhs, double *sol, double *cv, double *hs);
+/* surface_fluxes_kokkos.cc:5-107 and conserved_quantity_kokkos.cc:8-81.  The conservation wrapper of the reference
+   keeps its eight diagnostics in wrapper-local Views (and prints column 0); here they are returned:
+   diag [ncols][8] = dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad */
+void elmo_surface_fluxes(elmo_state *S, double dt);
+void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag);
 /* probes matching ref_harness.cc (the parts of this path the reference's headers build for) */
 void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out);
 void elmo_pdma(int64_t n, const int *snl, const double *lhs, double *rhs);
@@ -406,6 +415,44 @@ void elmo_st_phase_change_soisno(int snl, int ltype, double dtime, double dhsdT,
                                  double *qflx_snofrz, double *qflx_snow_melt, double *qflx_snomelt,
                                  double *eflx_snomelt, int *imelt, double *qflx_snofrz_lyr, double *h2osoi_ice,
                                  double *h2osoi_liq, double *t_soisno);
+
+/* surface fluxes and conservation diagnostics (elmo_physics_e.c) */
+void elmo_sf_initial_flux_calc(int urbpoi, int snl, double frac_sno_eff, double frac_h2osfc, double t_h2osfc_bef,
+                               double tssbef_snotop, double tssbef_soitop, double t_grnd, double cgrnds, double cgrndl,
+                               double *eflx_sh_grnd, double *qflx_evap_soi, double *qflx_ev_snow, double *qflx_ev_soil,
+                               double *qflx_ev_h2osfc);
+void elmo_sf_update_surface_fluxes(int urbpoi, int do_capsnow, int snl, double dtime, double t_grnd, double htvp,
+                                   double frac_sno_eff, double frac_h2osfc, double t_h2osfc_bef, double sabg_soil,
+                                   double sabg_snow, double dlrad, double frac_veg_nosno, double emg, double forc_lwrad,
+                                   double tssbef_snotop, double tssbef_soitop, double h2osoi_ice_snotop,
+                                   double h2osoi_liq_snotop, double eflx_sh_veg, double qflx_evap_veg,
+                                   double *qflx_evap_soi, double *eflx_sh_grnd, double *qflx_ev_snow,
+                                   double *qflx_ev_soil, double *qflx_ev_h2osfc, double *eflx_soil_grnd,
+                                   double *eflx_sh_tot, double *qflx_evap_tot, double *eflx_lh_tot, double *qflx_evap_grnd,
+                                   double *qflx_sub_snow, double *qflx_dew_snow, double *qflx_dew_grnd,
+                                   double *qflx_snwcp_liq, double *qflx_snwcp_ice);
+void elmo_sf_lwrad_outgoing(int urbpoi, int snl, int frac_veg_nosno, double forc_lwrad, double frac_sno_eff,
+                            double tssbef_snotop, double tssbef_soitop, double frac_h2osfc, double t_h2osfc_bef,
+                            double t_grnd, double ulrad, double emg, double *eflx_lwrad_out, double *eflx_lwrad_net);
+double elmo_sf_soil_energy_balance(int ctype, int snl, double eflx_soil_grnd, double xmf, double xmf_h2osfc,
+                                   double frac_h2osfc, double t_h2osfc, double t_h2osfc_bef, double dtime,
+                                   double eflx_h2osfc_to_snow, double frac_sno_eff, const double *t_soisno,
+                                   const double *tssbef, const double *fact);
+double elmo_ce_column_water_mass(double h2ocan, double h2osno, double h2osfc, const double *h2osoi_ice,
+                                 const double *h2osoi_liq);
+double elmo_ce_dh2o_dt(double begwb, double endwb, double dtime);
+double elmo_ce_column_water_balance_error(double begwb, double endwb, double hydrology_source_sink, double forc_rain,
+                                          double forc_snow, double qflx_evap_tot, double qflx_snwcp_ice, double dtime);
+double elmo_ce_snow_water_balance_error(int snl, double qflx_dew_snow, double qflx_dew_grnd, double qflx_sub_snow,
+                                        double qflx_evap_grnd, double qflx_snow_melt, double qflx_snwcp_ice,
+                                        double qflx_snwcp_liq, double qflx_sl_top_soil, double frac_sno_eff,
+                                        double qflx_rain_grnd, double qflx_snow_grnd, double qflx_h2osfc_ice,
+                                        double h2osno, double h2osno_old, double dtime, int do_capsnow);
+double elmo_ce_solar_shortwave_balance_error(double fsa, double fsr, const double *forc_solad, const double *forc_solai);
+double elmo_ce_solar_longwave_balance_error(double eflx_lwrad_out, double eflx_lwrad_net, double forc_lwrad);
+double elmo_ce_surface_energy_balance_error(double sabv, double sabg_chk, double forc_lwrad, double eflx_lwrad_out,
+                                            double eflx_sh_tot, double eflx_lh_tot, double eflx_soil_grnd);
+double elmo_ce_net_radiation(double fsa, double eflx_lwrad_net);
 
 /* surface albedo (surface_albedo_impl.hh) */
 void elmo_sa_init_timestep(int urbpoi, double elai, const double *mss_cnc_bcphi, const double *mss_cnc_bcpho,

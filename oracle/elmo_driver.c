@@ -449,6 +449,61 @@ void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs_out, double 
 
 void elmo_soil_temperature(elmo_state *S, double dt) { elmo_soil_temperature_ex(S, dt, NULL, NULL, NULL, NULL, NULL); }
 
+/* surface_fluxes_kokkos.cc:5-107 */
+void elmo_surface_fluxes(elmo_state *S, double dt)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int soitop = ELMO_NLEVSNO;
+    const int snotop = soitop - S->snl[c];
+    const int urbpoi = S->land.urbpoi;
+    elmo_sf_initial_flux_calc(urbpoi, S->snl[c], S->frac_sno_eff[c], S->frac_h2osfc[c], S->t_h2osfc_bef[c],
+                              LV(tssbef, 20)[snotop], LV(tssbef, 20)[soitop], S->t_grnd[c], S->cgrnds[c], S->cgrndl[c],
+                              &S->eflx_sh_grnd[c], &S->qflx_evap_soi[c], &S->qflx_ev_snow[c], &S->qflx_ev_soil[c],
+                              &S->qflx_ev_h2osfc[c]);
+    elmo_sf_update_surface_fluxes(urbpoi, S->do_capsnow[c], S->snl[c], dt, S->t_grnd[c], S->htvp[c], S->frac_sno_eff[c],
+                                  S->frac_h2osfc[c], S->t_h2osfc_bef[c], S->sabg_soil[c], S->sabg_snow[c], S->dlrad[c],
+                                  S->frac_veg_nosno[c], S->emg[c], S->forc_lwrad[c], LV(tssbef, 20)[snotop],
+                                  LV(tssbef, 20)[soitop], LV(h2osoi_ice, 20)[snotop], LV(h2osoi_liq, 20)[soitop],
+                                  S->eflx_sh_veg[c], S->qflx_evap_veg[c], &S->qflx_evap_soi[c], &S->eflx_sh_grnd[c],
+                                  &S->qflx_ev_snow[c], &S->qflx_ev_soil[c], &S->qflx_ev_h2osfc[c], &S->eflx_soil_grnd[c],
+                                  &S->eflx_sh_tot[c], &S->qflx_evap_tot[c], &S->eflx_lh_tot[c], &S->qflx_evap_grnd[c],
+                                  &S->qflx_sub_snow[c], &S->qflx_dew_snow[c], &S->qflx_dew_grnd[c], &S->qflx_snwcp_liq[c],
+                                  &S->qflx_snwcp_ice[c]);
+    elmo_sf_lwrad_outgoing(urbpoi, S->snl[c], S->frac_veg_nosno[c], S->forc_lwrad[c], S->frac_sno_eff[c],
+                           LV(tssbef, 20)[snotop], LV(tssbef, 20)[soitop], S->frac_h2osfc[c], S->t_h2osfc_bef[c],
+                           S->t_grnd[c], S->ulrad[c], S->emg[c], &S->eflx_lwrad_out[c], &S->eflx_lwrad_net[c]);
+    S->soil_e_balance[c] = elmo_sf_soil_energy_balance(S->land.ctype, S->snl[c], S->eflx_soil_grnd[c], S->xmf[c],
+                                                       S->xmf_h2osfc[c], S->frac_h2osfc[c], S->t_h2osfc[c],
+                                                       S->t_h2osfc_bef[c], dt, S->eflx_h2osfc_snow[c], S->frac_sno_eff[c],
+                                                       LV(t_soisno, 20), LV(tssbef, 20), LV(fact, 20));
+  }
+}
+
+/* conserved_quantity_kokkos.cc:8-81 */
+void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag)
+{
+  const double hydrology_source_sink = 0.0; /* hardwired (:22) */
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double *d = diag + (size_t)c * 8;
+    d[0] = elmo_ce_column_water_mass(S->h2ocan[c], S->h2osno[c], S->h2osfc[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20));
+    d[3] = elmo_ce_dh2o_dt(S->dtbegin_column_h2o[c], d[0], dt);
+    d[1] = elmo_ce_column_water_balance_error(S->dtbegin_column_h2o[c], d[0], hydrology_source_sink, S->forc_rain[c],
+                                              S->forc_snow[c], S->qflx_evap_tot[c], S->qflx_snwcp_ice[c], dt);
+    d[2] = elmo_ce_snow_water_balance_error(S->snl[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c], S->qflx_sub_snow[c],
+                                            S->qflx_evap_grnd[c], S->qflx_snow_melt[c], S->qflx_snwcp_ice[c],
+                                            S->qflx_snwcp_liq[c], S->qflx_sl_top_soil[c], S->frac_sno_eff[c],
+                                            S->qflx_rain_grnd[c], S->qflx_snow_grnd[c], S->qflx_h2osfc_ice[c],
+                                            S->h2osno[c], S->h2osno_old[c], dt, S->do_capsnow[c]);
+    d[4] = elmo_ce_solar_shortwave_balance_error(S->fsa[c], S->fsr[c], LV(forc_solad, 2), LV(forc_solai, 2));
+    d[5] = elmo_ce_solar_longwave_balance_error(S->eflx_lwrad_out[c], S->eflx_lwrad_net[c], S->forc_lwrad[c]);
+    d[6] = elmo_ce_surface_energy_balance_error(S->sabv[c], S->sabg_chk[c], S->forc_lwrad[c], S->eflx_lwrad_out[c],
+                                                S->eflx_sh_tot[c], S->eflx_lh_tot[c], S->eflx_soil_grnd[c]);
+    d[7] = elmo_ce_net_radiation(S->fsa[c], S->eflx_lwrad_net[c]);
+  }
+}
+
 /* counterparts of the ref_harness.cc probes elmref_soil_thermal / elmref_pdma / elmref_phase_change */
 void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out)
 {

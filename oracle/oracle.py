@@ -74,6 +74,8 @@ class _Lib:
         L.elmo_soil_temperature.argtypes = [C.c_void_p, C.c_double]
         L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
         L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
+        L.elmo_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.elmo_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
         L.elmo_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         self.ref = _load(os.path.join(HERE, "_ref", "libelmref.so"))
@@ -90,6 +92,9 @@ class _Lib:
                 R.elmref_soil_thermal.argtypes = [C.c_void_p] * 5
                 R.elmref_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
                 R.elmref_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+            if hasattr(R, "elmref_surface_fluxes"):
+                R.elmref_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
+                R.elmref_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
 
 
 _LIB = None
@@ -248,6 +253,17 @@ class OracleState:
                    hs=np.zeros((n, 4)))
         self._L.lib.elmo_soil_temperature_ex(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "sol", "cv", "hs")])
         return out
+
+    def surface_fluxes(self, dt, lib=None):
+        (self._L.lib.elmo_surface_fluxes if lib is None else lib.elmref_surface_fluxes)(self.ptr, float(dt))
+
+    DIAG_NAMES = ("dtend_column_h2o", "errh2o", "errh2osno", "dwb", "errsol", "errlon", "errseb", "netrad")
+
+    def evaluate_conservation(self, dt, lib=None):
+        """-> [ncols, 8] (DIAG_NAMES): the wrapper-local diagnostics of kokkos_evaluate_conservation."""
+        d = np.zeros((self.ncols, 8))
+        (self._L.lib.elmo_evaluate_conservation if lib is None else lib.elmref_evaluate_conservation)(self.ptr, float(dt), d.ctypes.data)
+        return d
 
     def soil_thermal(self, lib=None):
         """-> (thk, tk, cv [n,20], scal [n,3] = tk_h2osfc, c_h2osfc, dz_h2osfc); lib: the Reference's library instead."""

@@ -8,7 +8,7 @@
 // Covered: every hot-path header that compiles without netcdf-c:
 //   canopy_hydrology.h  surface_radiation.h  canopy_temperature.h (+qsat.h, surface_resistance.h)
 //   bareground_fluxes.h (+friction_velocity.h)  snow_snicar.h  soil_moist_stress.h  atm_physics.h
-//   soil_thermal_properties.h  pentadiagonal_solver.h  phase_change.h
+//   soil_thermal_properties.h  pentadiagonal_solver.h  phase_change.h  surface_fluxes.h  conserved_quantity_evaluators.h
 // Not covered (unbuildable here: pft_data.h -> read_input.hh -> read_netcdf.hh -> netcdf.h):
 //   canopy_fluxes.h  photosynthesis.h  surface_albedo.h
 // The loops below follow the argument wiring of driver/kokkos/*_kokkos.cc (cited per function).
@@ -31,6 +31,8 @@
 #include "pentadiagonal_solver.h"
 #include "phase_change.h"
 #include "soil_thermal_properties.h"
+#include "conserved_quantity_evaluators.h"
+#include "surface_fluxes.h"
 
 #include "elm_oracle.h"
 
@@ -363,6 +365,60 @@ void elmref_phase_change(elmo_state* S, double dt, const double* dhsdT, const do
                                         S->xmf[c], S->qflx_snofrz[c], S->qflx_snow_melt[c], S->qflx_snomelt[c],
                                         S->eflx_snomelt[c], AI1(20, S->imelt + (size_t)c * 20), V(qflx_snofrz_lyr, 5),
                                         V(h2osoi_ice, 20), V(h2osoi_liq, 20), V(t_soisno, 20));
+  }
+}
+
+// surface_fluxes_kokkos.cc:5-107
+void elmref_surface_fluxes(elmo_state* S, double dt)
+{
+  const bool urbpoi = S->land.urbpoi != 0;
+  for (int64_t c = 0; c < S->ncols; c++) {
+    const int soitop = 5;
+    const int snotop = soitop - S->snl[c];
+    double* tssbef = S->tssbef + (size_t)c * 20;
+    ELM::surface_fluxes::initial_flux_calc(urbpoi, S->snl[c], S->frac_sno_eff[c], S->frac_h2osfc[c], S->t_h2osfc_bef[c],
+                                           tssbef[snotop], tssbef[soitop], S->t_grnd[c], S->cgrnds[c], S->cgrndl[c],
+                                           S->eflx_sh_grnd[c], S->qflx_evap_soi[c], S->qflx_ev_snow[c], S->qflx_ev_soil[c],
+                                           S->qflx_ev_h2osfc[c]);
+    ELM::surface_fluxes::update_surface_fluxes(
+        urbpoi, S->do_capsnow[c], S->snl[c], dt, S->t_grnd[c], S->htvp[c], S->frac_sno_eff[c], S->frac_h2osfc[c],
+        S->t_h2osfc_bef[c], S->sabg_soil[c], S->sabg_snow[c], S->dlrad[c], S->frac_veg_nosno[c], S->emg[c], S->forc_lwrad[c],
+        tssbef[snotop], tssbef[soitop], S->h2osoi_ice[(size_t)c * 20 + snotop], S->h2osoi_liq[(size_t)c * 20 + soitop],
+        S->eflx_sh_veg[c], S->qflx_evap_veg[c], S->qflx_evap_soi[c], S->eflx_sh_grnd[c], S->qflx_ev_snow[c],
+        S->qflx_ev_soil[c], S->qflx_ev_h2osfc[c], S->eflx_soil_grnd[c], S->eflx_sh_tot[c], S->qflx_evap_tot[c],
+        S->eflx_lh_tot[c], S->qflx_evap_grnd[c], S->qflx_sub_snow[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c],
+        S->qflx_snwcp_liq[c], S->qflx_snwcp_ice[c]);
+    ELM::surface_fluxes::lwrad_outgoing(urbpoi, S->snl[c], S->frac_veg_nosno[c], S->forc_lwrad[c], S->frac_sno_eff[c],
+                                        tssbef[snotop], tssbef[soitop], S->frac_h2osfc[c], S->t_h2osfc_bef[c], S->t_grnd[c],
+                                        S->ulrad[c], S->emg[c], S->eflx_lwrad_out[c], S->eflx_lwrad_net[c]);
+    S->soil_e_balance[c] = ELM::surface_fluxes::soil_energy_balance(
+        S->land.ctype, S->snl[c], S->eflx_soil_grnd[c], S->xmf[c], S->xmf_h2osfc[c], S->frac_h2osfc[c], S->t_h2osfc[c],
+        S->t_h2osfc_bef[c], dt, S->eflx_h2osfc_snow[c], S->frac_sno_eff[c], V(t_soisno, 20), V(tssbef, 20), V(fact, 20));
+  }
+}
+
+// conserved_quantity_kokkos.cc:8-81; diag [ncols][8] = dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad
+void elmref_evaluate_conservation(elmo_state* S, double dt, double* diag)
+{
+  const double hydrology_source_sink = 0.0;
+  for (int64_t c = 0; c < S->ncols; c++) {
+    double* d = diag + (size_t)c * 8;
+    d[0] = ELM::conservation_eval::column_water_mass(S->h2ocan[c], S->h2osno[c], S->h2osfc[c], V(h2osoi_ice, 20),
+                                                     V(h2osoi_liq, 20));
+    d[3] = ELM::conservation_eval::dh2o_dt(S->dtbegin_column_h2o[c], d[0], dt);
+    d[1] = ELM::conservation_eval::column_water_balance_error(S->dtbegin_column_h2o[c], d[0], hydrology_source_sink,
+                                                              S->forc_rain[c], S->forc_snow[c], S->qflx_evap_tot[c],
+                                                              S->qflx_snwcp_ice[c], dt);
+    d[2] = ELM::conservation_eval::snow_water_balance_error(
+        S->snl[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c], S->qflx_sub_snow[c], S->qflx_evap_grnd[c], S->qflx_snow_melt[c],
+        S->qflx_snwcp_ice[c], S->qflx_snwcp_liq[c], S->qflx_sl_top_soil[c], S->frac_sno_eff[c], S->qflx_rain_grnd[c],
+        S->qflx_snow_grnd[c], S->qflx_h2osfc_ice[c], S->h2osno[c], S->h2osno_old[c], dt, S->do_capsnow[c] != 0);
+    d[4] = ELM::conservation_eval::solar_shortwave_balance_error(S->fsa[c], S->fsr[c], V(forc_solad, 2), V(forc_solai, 2));
+    d[5] = ELM::conservation_eval::solar_longwave_balance_error(S->eflx_lwrad_out[c], S->eflx_lwrad_net[c], S->forc_lwrad[c]);
+    d[6] = ELM::conservation_eval::surface_energy_balance_error(S->sabv[c], S->sabg_chk[c], S->forc_lwrad[c],
+                                                                S->eflx_lwrad_out[c], S->eflx_sh_tot[c], S->eflx_lh_tot[c],
+                                                                S->eflx_soil_grnd[c]);
+    d[7] = ELM::conservation_eval::net_radiation(S->fsa[c], S->eflx_lwrad_net[c]);
   }
 }
 } // extern "C"

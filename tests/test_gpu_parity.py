@@ -312,3 +312,43 @@ def test_soil_temperature_next_row(tier, n, seed):
         im = np.bincount(D["imelt"].ravel(), minlength=3)
         assert im[1] > 0 and im[2] > 0 and set(np.unique(D["snl"])) == {0, 1, 2, 3, 4, 5}
     D.close()
+
+
+def test_surface_fluxes_and_conservation_diagnostics():
+    """kokkos_surface_fluxes and kokkos_evaluate_conservation (the calls after soil_temperature), on inputs
+    re-synchronised from the oracle; the device (min, max, sum) of the eight diagnostics against numpy."""
+    n = 20000
+    D, S = _pair(n, "B", 51)
+    st.timestep7(D, DT)
+    S.timestep7(DT)
+    S.soil_temperature(DT)
+    for k, v in S.fields.items():
+        if k != "err_flags":
+            D[k] = v
+    st.kokkos_surface_fluxes(D, DT)
+    S.surface_fluxes(DT)
+    names = ["eflx_sh_grnd", "qflx_evap_soi", "qflx_ev_snow", "qflx_ev_soil", "qflx_ev_h2osfc", "eflx_soil_grnd", "eflx_sh_tot",
+             "qflx_evap_tot", "eflx_lh_tot", "qflx_evap_grnd", "qflx_sub_snow", "qflx_dew_snow", "qflx_dew_grnd",
+             "qflx_snwcp_liq", "qflx_snwcp_ice", "eflx_lwrad_out", "eflx_lwrad_net", "soil_e_balance"]
+    # soil_e_balance, eflx_soil_grnd: sums / differences of O(1e3) W/m2 terms (and of the reference's t_h2osfc^40 term
+    # where water ponds): floor relative to the operands
+    # eflx_lwrad_net = outgoing - incoming longwave, both ~ 3e2 W/m2
+    scale = {"soil_e_balance": 1e4, "eflx_soil_grnd": 1e4, "qflx_sub_snow": 1e-3, "qflx_evap_grnd": 1e-3, "eflx_lwrad_net": 1e3}
+    ponded = S["frac_h2osfc"] != 0  # pow(t_h2osfc_bef, 40) ~ 1e97 there: compare relatively, separately
+    worst, bad = H.compare_states(D, S, names=names, extra_scale=scale, skip_cols=ponded)
+    assert not bad, bad
+    worst, bad = H.compare_states(D, S, names=[k for k in names if k not in ("soil_e_balance",)], extra_scale=scale,
+                                  skip_cols=~ponded)
+    assert not bad, bad
+    others = [k for k in S.fields if k not in names and k != "err_flags"]
+    worst, bad = H.compare_states(D, S, names=others, rel=0.0, newton=False)
+    assert not bad, bad
+    for k in names:  # the conservation wrapper reads identical bits
+        D[k] = S.fields[k]
+    mms, cols = st.kokkos_evaluate_conservation(D, DT, per_column=True)
+    ref = S.evaluate_conservation(DT)
+    e = np.abs(cols - ref) / np.maximum(np.abs(ref), 1e-6)
+    assert e[~ponded].max() < 1e-12 and e[ponded][:, [0, 1, 2, 3, 4, 5, 7]].max() < 1e-12
+    assert np.array_equal(mms[:, 0], cols.min(axis=0)) and np.array_equal(mms[:, 1], cols.max(axis=0))
+    assert np.allclose(mms[:, 2], cols.sum(axis=0), rtol=1e-12, atol=1e-12 * np.abs(cols).sum(axis=0).max())
+    D.close()

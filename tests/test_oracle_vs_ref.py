@@ -240,3 +240,21 @@ def test_phase_change_bitwise(soil_states):
     im = np.bincount(A["imelt"].ravel(), minlength=3)
     assert im[1] > 1000 and im[2] > 1000 and (A["qflx_h2osfc_ice"] != 0).sum() > 100  # melting, freezing, pond freezing
     assert (A["qflx_snomelt"] > 0).any() and (A["qflx_snofrz"] > 0).any()
+
+
+# ---- rank 2 of the next rows: surface fluxes after the temperature solve, and the conservation diagnostics
+def test_surface_fluxes_and_conservation_bitwise(soil_states):
+    A = soil_states.clone()
+    A.soil_temperature(1800.0)
+    B = A.clone()
+    A.surface_fluxes(1800.0)
+    B.surface_fluxes(1800.0, lib=O.Reference().R)
+    assert not _same(A, B)
+    da = A.evaluate_conservation(1800.0)
+    db = B.evaluate_conservation(1800.0, lib=O.Reference().R)
+    assert np.array_equal(da, db, equal_nan=True)
+    # the branches: evaporation limited by the top layer's water, dew on snow / on ground, sublimation, capped snow
+    assert (A["qflx_dew_snow"] > 0).any() and (A["qflx_dew_grnd"] > 0).any() and (A["qflx_sub_snow"] > 0).any()
+    assert (A["qflx_evap_grnd"] > 0).any() and np.isfinite(da[:, [0, 1, 3, 4, 5, 7]]).all()
+    # shortwave and longwave closures hold to rounding for every column (the physics upstream is consistent)
+    assert np.abs(da[:, 4]).max() < 1e-9 and np.abs(da[:, 5]).max() < 1e-9

@@ -40,11 +40,18 @@ def _worker(rank, world, port, out_dir):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(el, op=dist.ReduceOp.MAX)  # the bench's max-over-ranks
+    # the one natural collective: global (min, max, sum) of the conservation diagnostics
+    from elmkernels_amd import diagnostics
+
+    S.soil_temperature(1800.0)
+    S.surface_fluxes(1800.0)
+    diag = S.evaluate_conservation(1800.0)
+    gmms = diagnostics.global_min_max_sum(diagnostics.local_min_max_sum(diag))
     sizes = torch.zeros(world, dtype=torch.int64)
     sizes[rank] = count
     dist.all_reduce(sizes)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), start=start, count=count, t_veg=S["t_veg"], cgrnd=S["cgrnd"],
-             snl=S["snl"], albd=S["albd"], elapsed=float(el.item()), sizes=sizes.numpy())
+             snl=S["snl"], albd=S["albd"], elapsed=float(el.item()), sizes=sizes.numpy(), gmms=gmms)
     dist.destroy_process_group()
 
 
@@ -67,3 +74,12 @@ def test_two_rank_block_split(tmp_path):
     for name in ("t_veg", "cgrnd", "snl", "albd"):
         whole = np.concatenate([p[name] for p in parts])
         assert np.array_equal(whole, S[name], equal_nan=True), name
+    # every rank holds the same global diagnostics, equal to those of the undivided domain
+    from elmkernels_amd import diagnostics
+
+    S.soil_temperature(1800.0)
+    S.surface_fluxes(1800.0)
+    ref = diagnostics.local_min_max_sum(S.evaluate_conservation(1800.0))
+    assert np.array_equal(parts[0]["gmms"], parts[1]["gmms"])
+    assert np.array_equal(parts[0]["gmms"][:, :2], ref[:, :2])  # min, max: exact
+    assert np.allclose(parts[0]["gmms"][:, 2], ref[:, 2], rtol=1e-12, atol=1e-9)  # sum: association differs

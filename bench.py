@@ -163,22 +163,11 @@ def timed_steps(D, workload, steps, warmup, sync_all, dist, torch):
 
 
 def event_time_soil(D, nsteps):
-    """Mean device time of the soil_temperature kernel: HIP events are not exposed for it, so time the launches
-    back to back on the context's stream between two host synchronisations (restore excluded by subtraction)."""
+    """Mean device time of the soil_temperature launch: HIP events on the context's stream (elmk_profile_wrapper), the
+    snapshot restored before every launch outside the event brackets."""
     from elmkernels_amd import state as st
 
-    D.sync()
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        D.restore_fields()
-    D.sync()
-    t_restore = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        D.restore_fields()
-        st.kokkos_soil_temperature(D, 1800.0)
-    D.sync()
-    return max(1e-9, (time.perf_counter() - t0 - t_restore) / nsteps) * 1e3
+    return D.profile_wrapper(st.WRAPPER_NAMES.index("soil_temperature"), 1800.0, nsteps)
 
 
 def main():
@@ -322,7 +311,7 @@ def main():
         out["device_state_GB"] = state_gb
         if other is not None:
             out["other_tier"] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(host_state, workload=args.workload)
         print(json.dumps(out))
     if dist is not None:

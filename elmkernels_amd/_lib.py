@@ -52,6 +52,7 @@ SIGNATURES = {
     "elmk_error_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]),
     "elmk_clear_errors": (C.c_int, [_P]),
     "elmk_profile_timestep7": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "elmk_profile_wrapper": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "elmk_read_scratch": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64]),
     "elmk_copy_bandwidth": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
 }

@@ -689,6 +689,43 @@ int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_k
   return ELMK_OK;
 }
 
+int elmk_profile_wrapper(elmk_ctx* ctx, int wrapper, double dt, int nsteps, float* ms_mean)
+{
+  PHYSICS_PROLOGUE();
+  if (nsteps <= 0 || !ms_mean) return invalid(ctx, "elmk_profile_wrapper: bad arguments");
+  if (wrapper < 0 || wrapper > ELMK_WRAPPER_SURFACE_FLUXES) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
+  std::vector<hipEvent_t> ev((size_t)nsteps * 2);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  for (int s = 0; s < nsteps; s++) {
+    if (!ctx->snap_fields.empty())
+      if (int rc = elmk_restore_fields(ctx)) return rc;
+    HIPCHK(hipEventRecord(ev[(size_t)s * 2], ctx->stream));
+    switch (wrapper) {
+      case ELMK_WRAPPER_FRAC_WET: launch_frac_wet(ctx->d, ctx->ncols, ctx->stream); break;
+      case ELMK_WRAPPER_ALBEDO_SNICAR: launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side); break;
+      case ELMK_WRAPPER_CANOPY_HYDROLOGY: launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream); break;
+      case ELMK_WRAPPER_SURFACE_RADIATION: launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream); break;
+      case ELMK_WRAPPER_CANOPY_TEMPERATURE: launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream); break;
+      case ELMK_WRAPPER_BAREGROUND_FLUXES: launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream); break;
+      case ELMK_WRAPPER_CANOPY_FLUXES: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
+      case ELMK_WRAPPER_SOIL_TEMPERATURE: launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream); break;
+      default: launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
+    }
+    HIPCHK(hipEventRecord(ev[(size_t)s * 2 + 1], ctx->stream));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double acc = 0.0;
+  for (int s = 0; s < nsteps; s++) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)s * 2], ev[(size_t)s * 2 + 1]));
+    acc += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *ms_mean = (float)(acc / nsteps);
+  return ELMK_OK;
+}
+
 int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64_t count)
 {
   if (int rc = enter(ctx)) return rc;

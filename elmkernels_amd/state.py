@@ -210,12 +210,20 @@ class ELMState:
         self._chk(self.lib.elmk_read_scratch(self.ctx, 1, out.ctypes.data_as(C.c_void_p), int(offset), int(count)), "read_scratch")
         return out
 
+    def profile_wrapper(self, wrapper, dt, nsteps=5):
+        """Mean device time (ms, HIP events on the launch stream) of one wrapper; wrapper: index into WRAPPER_NAMES."""
+        ms = C.c_float()
+        self._chk(self.lib.elmk_profile_wrapper(self.ctx, int(wrapper), float(dt), int(nsteps), C.byref(ms)), "profile_wrapper")
+        return ms.value
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=20):
         g = C.c_double()
         self._chk(self.lib.elmk_copy_bandwidth(self.ctx, int(nbytes), int(iters), C.byref(g)), "copy_bandwidth")
         return g.value
 
 
+WRAPPER_NAMES = ["frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
+                 "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes"]
 KERNEL_NAMES = [
     "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
     "bareground_fluxes", "canopy_fluxes",

@@ -208,6 +208,14 @@ int elmk_clear_errors(elmk_ctx *ctx);
  * time of one whole timestep (first event to last).  If a snapshot exists (elmk_snapshot_fields) it is
  * restored before every step, outside the event brackets, so each profiled step does the same work. */
 int elmk_profile_timestep7(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_kernel, float *ms_total);
+/* the same for one wrapper: mean device time over nsteps launches, HIP events on the context's stream, the snapshot (if
+ * any) restored before every launch outside the event brackets */
+typedef enum {
+  ELMK_WRAPPER_FRAC_WET = 0, ELMK_WRAPPER_ALBEDO_SNICAR, ELMK_WRAPPER_CANOPY_HYDROLOGY, ELMK_WRAPPER_SURFACE_RADIATION,
+  ELMK_WRAPPER_CANOPY_TEMPERATURE, ELMK_WRAPPER_BAREGROUND_FLUXES, ELMK_WRAPPER_CANOPY_FLUXES,
+  ELMK_WRAPPER_SOIL_TEMPERATURE, ELMK_WRAPPER_SURFACE_FLUXES
+} elmk_wrapper;
+int elmk_profile_wrapper(elmk_ctx *ctx, int wrapper, double dt, int nsteps, float *ms_mean);
 /* Read back context-owned scratch (diagnostics; not part of the state contract).
  *   ELMK_SCRATCH_CF_TRIPS: int32 per column - trips of the leaf-temperature iteration
  *                          (canopy_fluxes_impl.hh:233-450) in the last elmk_canopy_fluxes call, 0 = not vegetated

@@ -76,6 +76,9 @@ struct PsnTemp {
 // the by-reference argument pack of ci_func / brent / hybrid
 struct CiCtx {
   double gb_mol, je, cair, oair, lmr_z, par_z, rh_can, vcmax_z, forc_pbot, cp, kc, ko, qe, tpu_z, kp_z, theta_cj, bbb, mbb;
+  // sub-expressions of ci_func that do not depend on ci, evaluated once per solve instead of once per call (same
+  // operands, same operations: kc * (1.0 + oair / ko) of :316 and 1.4 / gb_mol of :352)
+  double kc_o, r14_gb;
   bool c3flag;
   double gs_mol, ac, aj, ap, ag, an;
   uint32_t err;
@@ -86,7 +89,7 @@ __device__ __forceinline__ double ci_func(double ci, CiCtx& k)
 {
   const double theta_ip = 0.95;
   if (k.c3flag) {
-    k.ac = k.vcmax_z * dmax(ci - k.cp, 0.0) / (ci + k.kc * (1.0 + k.oair / k.ko));
+    k.ac = k.vcmax_z * dmax(ci - k.cp, 0.0) / (ci + k.kc_o);
     k.aj = k.je * dmax(ci - k.cp, 0.0) / (4.0 * ci + 8.0 * k.cp);
     k.ap = 3.0 * k.tpu_z;
   } else {
@@ -101,7 +104,7 @@ __device__ __forceinline__ double ci_func(double ci, CiCtx& k)
   k.ag = dmin(r1, r2);
   k.an = k.ag - k.lmr_z;
   if (k.an < 0.0) return 0.0;
-  double cs = k.cair - 1.4 / k.gb_mol * k.an * k.forc_pbot;
+  double cs = k.cair - k.r14_gb * k.an * k.forc_pbot;
   cs = dmax(cs, 1.e-6);
   const double aquad = cs;
   const double bquad = cs * (k.gb_mol - k.bbb) - k.mbb * k.an * k.forc_pbot;
@@ -337,6 +340,8 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
     k.bbb = bbb;
     k.mbb = I.mbbopt;
     k.c3flag = I.c3flag;
+    k.kc_o = k.kc * (1.0 + k.oair / k.ko);
+    k.r14_gb = 1.4 / k.gb_mol;
     k.gs_mol = 0.0;
     k.ac = k.aj = k.ap = k.ag = k.an = 0.0;
     k.err = 0;
@@ -345,7 +350,7 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
     double gs_mol = k.gs_mol;
     const double an = k.an;
     if (an < 0.0) gs_mol = bbb;
-    double cs = cair - 1.4 / gb_mol * an * forc_pbot;
+    double cs = cair - k.r14_gb * an * forc_pbot;
     cs = dmax(cs, 1.0e-6);
     const double gs = gs_mol / I.cf;
     rs_z = dmin(1.0 / gs, rsmax0);

@@ -15,6 +15,7 @@ from .state import (  # noqa: F401
     kokkos_canopy_fluxes,
     kokkos_soil_temperature,
     kokkos_surface_fluxes,
+    kokkos_init_timestep,
     kokkos_evaluate_conservation,
     kokkos_canopy_hydrology,
     kokkos_canopy_temperature,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "elmk_timestep7": (C.c_int, [_P, C.c_double]),
     "elmk_soil_temperature": (C.c_int, [_P, C.c_double]),
     "elmk_surface_fluxes": (C.c_int, [_P, C.c_double]),
+    "elmk_init_timestep": (C.c_int, [_P]),
     "elmk_evaluate_conservation": (C.c_int, [_P, C.c_double, _P, _P]),
     "elmk_error_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]),
     "elmk_clear_errors": (C.c_int, [_P]),

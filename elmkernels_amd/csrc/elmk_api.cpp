@@ -574,6 +574,14 @@ int elmk_soil_temperature(elmk_ctx* ctx, double dt)
   return ELMK_OK;
 }
 
+int elmk_init_timestep(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  launch_init_timestep(ctx->d, ctx->ncols, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
 int elmk_surface_fluxes(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();

@@ -32,6 +32,7 @@ void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_
 // surface fluxes after the solve, conservation diagnostics reduced to (min, max, sum)
 constexpr int ELMK_CONS_NPART = 512;  // stage-1 partials per diagnostic
 void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+void launch_init_timestep(const DevState* S, int64_t n, hipStream_t st);
 void launch_conservation(const DevState* S, int64_t n, int64_t ld, double dt, const double* diag, double* part, double* out,
                          hipStream_t st);
 

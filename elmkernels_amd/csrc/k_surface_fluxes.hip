@@ -1,4 +1,5 @@
-// k_surface_fluxes.hip - the two short wrappers that close the budgets after the temperature solve:
+// k_surface_fluxes.hip - the short streaming wrappers around the budgets: the per-column part of kokkos_init_timestep
+// at the start of a step, and the two that close the budgets after the temperature solve:
 //   kokkos_surface_fluxes        driver/kokkos/surface_fluxes_kokkos.cc:5-107
 //     surface_fluxes::initial_flux_calc :73, update_surface_fluxes :147, lwrad_outgoing :247, soil_energy_balance :268
 //                                                            (src/physics/surface_fluxes_impl.hh)
@@ -261,6 +262,39 @@ __global__ __launch_bounds__(256) void k_cons_reduce2(const double* __restrict__
     out[k * 3 + 1] = s_max[0];
     out[k * 3 + 2] = s_sum[0];
   }
+}
+
+// ---- the per-column kernel of kokkos_init_timestep (init_timestep_kokkos.cc:55-75): h2osno_old, the column water
+//      mass the conservation check starts from, ELM::init_timestep (src/physics/init_timestep_impl.hh:7-42)
+__global__ __launch_bounds__(256) void k_init_timestep(const DevState* __restrict__ S)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  if (c >= S->ncols) return;
+  const double h2osno = S->h2osno[c];
+  S->h2osno_old[c] = h2osno;
+  double water = S->h2ocan[c] + h2osno + S->h2osfc[c];
+#pragma unroll 1
+  for (int i = 0; i < NLEVTOT; ++i) water += LV(h2osoi_ice, i) + LV(h2osoi_liq, i);
+  S->dtbegin_column_h2o[c] = water;
+  S->do_capsnow[c] = (h2osno > 1000.0) ? 1 : 0;  // H2OSNO_MAX (elm_constants.h)
+  S->frac_veg_nosno[c] = S->veg_active[c] ? S->frac_veg_nosno_alb[c] : 0;
+  if (!S->land.lakpoi) {
+    const int snl = S->snl[c];
+#pragma unroll
+    for (int i = 0; i < NLEVSNO; i++) {
+      if (i >= NLEVSNO - snl) {
+        const double ice = LV(h2osoi_ice, i);
+        LV(frac_iceold, i) = ice / (LV(h2osoi_liq, i) + ice);
+      }
+    }
+  }
+}
+
+void launch_init_timestep(const DevState* S, int64_t n, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_init_timestep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S);
 }
 
 void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st)

@@ -264,6 +264,11 @@ def kokkos_soil_temperature(S, dt):
     S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")
 
 
+def kokkos_init_timestep(S):
+    """The per-column kernel of kokkos_init_timestep (init_timestep_kokkos.cc:55-75)."""
+    S._chk(S.lib.elmk_init_timestep(S.ctx), "init_timestep")
+
+
 def kokkos_surface_fluxes(S, dt):
     """surface_fluxes_kokkos.cc:5-107 (follows soil_temperature in ELMInterface::advance)."""
     S._chk(S.lib.elmk_surface_fluxes(S.ctx, float(dt)), "surface_fluxes")

@@ -234,4 +234,6 @@ def make_state(field_table, n, tier="A", seed=0x5EEDE1A0, perturb=True):
         cols["dtbegin_column_h2o"] = (cols["h2ocan"] + cols["h2osno"] + cols["h2osfc"]
                                       + (cols["h2osoi_ice"] + cols["h2osoi_liq"]).sum(axis=1))
         cols["h2osno_old"] = cols["h2osno"].copy()
+    if "frac_veg_nosno_alb" in cols:
+        cols["frac_veg_nosno_alb"] = cols["frac_veg_nosno"].copy()
     return cols, scal, soil

@@ -191,6 +191,10 @@ int elmk_soil_temperature(elmk_ctx *ctx, double dt);
 /* kokkos_surface_fluxes(S, dt) (surface_fluxes_kokkos.cc:5-107): flux corrections for the new ground temperature,
  * ground heat flux, total fluxes, dew / sublimation partition, outgoing longwave, soil energy balance */
 int elmk_surface_fluxes(elmk_ctx *ctx, double dt);
+/* the per-column kernel at the end of kokkos_init_timestep (init_timestep_kokkos.cc:55-75): h2osno_old,
+ * dtbegin_column_h2o (what the conservation check starts from), snow capping flag, frac_veg_nosno, frac_iceold.
+ * (The forcing / phenology readers before it in that wrapper are I/O and stay with the caller.) */
+int elmk_init_timestep(elmk_ctx *ctx);
 /* kokkos_evaluate_conservation(S, dt) (conserved_quantity_kokkos.cc:8-81).  The reference keeps its eight
  * diagnostics in wrapper-local Views and prints column 0; here min_max_sum[8][3] receives (min, max, sum) over the
  * context's columns of dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad - what a multi-GPU

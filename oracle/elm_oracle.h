@@ -148,7 +148,8 @@ typedef struct {
   /* surface_fluxes + conservation diagnostics: elm_state.h / elm_state_impl.hh:146,297-345 */               \
   X(eflx_soil_grnd, D, 1) X(eflx_lwrad_out, D, 1) X(eflx_lwrad_net, D, 1) X(qflx_evap_grnd, D, 1)            \
   X(qflx_sub_snow, D, 1) X(qflx_dew_snow, D, 1) X(qflx_dew_grnd, D, 1) X(soil_e_balance, D, 1)               \
-  X(dtbegin_column_h2o, D, 1) X(h2osno_old, D, 1) X(qflx_sl_top_soil, D, 1)
+  X(dtbegin_column_h2o, D, 1) X(h2osno_old, D, 1) X(qflx_sl_top_soil, D, 1)                                  \
+  X(frac_veg_nosno_alb, I, 1)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -216,6 +217,9 @@ void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs, double *rhs
    keeps its eight diagnostics in wrapper-local Views (and prints column 0); here they are returned:
    diag [ncols][8] = dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad */
 void elmo_surface_fluxes(elmo_state *S, double dt);
+/* the per-column kernel of kokkos_init_timestep (init_timestep_kokkos.cc:55-75): h2osno_old, dtbegin_column_h2o,
+   ELM::init_timestep (init_timestep_impl.hh:7-42) */
+void elmo_init_timestep(elmo_state *S);
 void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag);
 /* probes matching ref_harness.cc (the parts of this path the reference's headers build for) */
 void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out);

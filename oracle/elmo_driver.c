@@ -480,6 +480,27 @@ void elmo_surface_fluxes(elmo_state *S, double dt)
   }
 }
 
+/* init_timestep_kokkos.cc:55-75 with ELM::init_timestep (src/physics/init_timestep_impl.hh:7-42) */
+void elmo_init_timestep(elmo_state *S)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    S->h2osno_old[c] = S->h2osno[c];
+    S->dtbegin_column_h2o[c] =
+        elmo_ce_column_water_mass(S->h2ocan[c], S->h2osno[c], S->h2osfc[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20));
+    const double H2OSNO_MAX = 1000.0; /* elm_constants.h */
+    S->do_capsnow[c] = (S->h2osno[c] > H2OSNO_MAX) ? 1 : 0;
+    S->frac_veg_nosno[c] = S->veg_active[c] ? S->frac_veg_nosno_alb[c] : 0;
+    if (!S->land.lakpoi) {
+      for (int i = 0; i < ELMO_NLEVSNO; i++) {
+        if (i >= ELMO_NLEVSNO - S->snl[c]) {
+          LV(frac_iceold, 20)[i] = LV(h2osoi_ice, 20)[i] / (LV(h2osoi_liq, 20)[i] + LV(h2osoi_ice, 20)[i]);
+        }
+      }
+    }
+  }
+}
+
 /* conserved_quantity_kokkos.cc:8-81 */
 void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag)
 {

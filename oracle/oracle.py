@@ -75,6 +75,7 @@ class _Lib:
         L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
         L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
         L.elmo_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_init_timestep.argtypes = [C.c_void_p]
         L.elmo_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.elmo_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
         L.elmo_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
@@ -94,6 +95,8 @@ class _Lib:
                 R.elmref_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
             if hasattr(R, "elmref_surface_fluxes"):
                 R.elmref_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
+            if hasattr(R, "elmref_init_timestep"):
+                R.elmref_init_timestep.argtypes = [C.c_void_p]
                 R.elmref_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
 
 
@@ -253,6 +256,9 @@ class OracleState:
                    hs=np.zeros((n, 4)))
         self._L.lib.elmo_soil_temperature_ex(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "sol", "cv", "hs")])
         return out
+
+    def init_timestep(self, lib=None):
+        (self._L.lib.elmo_init_timestep if lib is None else lib.elmref_init_timestep)(self.ptr)
 
     def surface_fluxes(self, dt, lib=None):
         (self._L.lib.elmo_surface_fluxes if lib is None else lib.elmref_surface_fluxes)(self.ptr, float(dt))

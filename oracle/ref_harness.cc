@@ -33,6 +33,7 @@
 #include "soil_thermal_properties.h"
 #include "conserved_quantity_evaluators.h"
 #include "surface_fluxes.h"
+#include "init_timestep.h"
 
 #include "elm_oracle.h"
 
@@ -419,6 +420,18 @@ void elmref_evaluate_conservation(elmo_state* S, double dt, double* diag)
                                                                 S->eflx_lwrad_out[c], S->eflx_sh_tot[c], S->eflx_lh_tot[c],
                                                                 S->eflx_soil_grnd[c]);
     d[7] = ELM::conservation_eval::net_radiation(S->fsa[c], S->eflx_lwrad_net[c]);
+  }
+}
+
+// init_timestep_kokkos.cc:55-75: the per-column kernel of kokkos_init_timestep
+void elmref_init_timestep(elmo_state* S)
+{
+  for (int64_t c = 0; c < S->ncols; c++) {
+    S->h2osno_old[c] = S->h2osno[c];
+    S->dtbegin_column_h2o[c] = ELM::conservation_eval::column_water_mass(S->h2ocan[c], S->h2osno[c], S->h2osfc[c],
+                                                                          V(h2osoi_ice, 20), V(h2osoi_liq, 20));
+    ELM::init_timestep(S->land.lakpoi != 0, S->veg_active[c] != 0, S->frac_veg_nosno_alb[c], S->snl[c], S->h2osno[c],
+                       V(h2osoi_ice, 20), V(h2osoi_liq, 20), S->do_capsnow[c], S->frac_veg_nosno[c], V(frac_iceold, 20));
   }
 }
 } // extern "C"

@@ -352,3 +352,13 @@ def test_surface_fluxes_and_conservation_diagnostics():
     assert np.array_equal(mms[:, 0], cols.min(axis=0)) and np.array_equal(mms[:, 1], cols.max(axis=0))
     assert np.allclose(mms[:, 2], cols.sum(axis=0), rtol=1e-12, atol=1e-12 * np.abs(cols).sum(axis=0).max())
     D.close()
+
+
+def test_init_timestep_column_kernel():
+    """The per-column kernel of kokkos_init_timestep: exact fields, the column water mass to summation order."""
+    D, S = _pair(5000, "B", 61)
+    st.kokkos_init_timestep(D)
+    S.init_timestep()
+    worst, bad = H.compare_states(D, S)
+    assert not bad, bad
+    D.close()

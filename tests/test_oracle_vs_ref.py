@@ -258,3 +258,11 @@ def test_surface_fluxes_and_conservation_bitwise(soil_states):
     assert (A["qflx_evap_grnd"] > 0).any() and np.isfinite(da[:, [0, 1, 3, 4, 5, 7]]).all()
     # shortwave and longwave closures hold to rounding for every column (the physics upstream is consistent)
     assert np.abs(da[:, 4]).max() < 1e-9 and np.abs(da[:, 5]).max() < 1e-9
+
+
+def test_init_timestep_column_kernel_bitwise(states):
+    A, B = states[0].clone(), states[0].clone()
+    A.init_timestep()
+    B.init_timestep(lib=O.Reference().R)
+    assert not _same(A, B)
+    assert np.array_equal(A["h2osno_old"], A["h2osno"]) and (A["do_capsnow"] == (A["h2osno"] > 1000.0)).all()

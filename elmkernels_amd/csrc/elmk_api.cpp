@@ -790,4 +790,27 @@ int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_
   return ELMK_OK;
 }
 
+int elmk_math_eval(elmk_ctx* ctx, int fn, const double* x, const double* y, double* out, int64_t n)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (fn < ELMK_MATH_EXP || fn > ELMK_MATH_POW || !x || !out || n < 0 || (fn >= ELMK_MATH_DIV && !y))
+    return invalid(ctx, "elmk_math_eval: bad arguments");
+  if (n == 0) return ELMK_OK;
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)n * 8 * 3));
+  int rc = ELMK_OK;
+  if (hip_fail(ctx, hipMemcpyAsync(d, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync")) rc = ELMK_E_HIP;
+  if (!rc && fn >= ELMK_MATH_DIV &&
+      hip_fail(ctx, hipMemcpyAsync(d + n, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync"))
+    rc = ELMK_E_HIP;
+  if (!rc) {
+    launch_math_eval(fn, d, d + n, d + 2 * n, n, ctx->stream);
+    if (hip_fail(ctx, hipMemcpyAsync(out, d + 2 * n, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync") ||
+        hip_fail(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize"))
+      rc = ELMK_E_HIP;
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
 }  // extern "C"

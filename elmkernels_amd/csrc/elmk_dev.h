@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "elmk.h"
+#include "elmk_math.h"  // exp / log / pow / log10 / atan with the bits of the host libm the reference runs on
 
 namespace elmk {
 
@@ -251,12 +252,12 @@ __device__ __forceinline__ double stab1(double zeta)
 {
   const double chik2 = sqrt(1.0 - 16.0 * zeta);
   const double chik = sqrt(chik2);
-  return 2.0 * log((1.0 + chik) * 0.5) + log((1.0 + chik2) * 0.5) - 2.0 * atan(chik) + ELM_PI * 0.5;
+  return 2.0 * elmk_log((1.0 + chik) * 0.5) + elmk_log((1.0 + chik2) * 0.5) - 2.0 * elmk_atan(chik) + ELM_PI * 0.5;
 }
 __device__ __forceinline__ double stab2(double zeta)
 {
   const double chik2 = sqrt(1.0 - 16.0 * zeta);
-  return 2.0 * log((1.0 + chik2) * 0.5);
+  return 2.0 * elmk_log((1.0 + chik2) * 0.5);
 }
 
 // :36-61
@@ -272,10 +273,10 @@ __device__ __forceinline__ void monin_obukhov_length(double ur, double thv, doub
   const double rib = GRAV * zldis * dthv / (thv * um * um);
   double zeta;
   if (rib >= 0.0) {
-    zeta = rib * log(zldis / z0m) / (1.0 - 5.0 * dmin(rib, 0.19));
+    zeta = rib * elmk_log(zldis / z0m) / (1.0 - 5.0 * dmin(rib, 0.19));
     zeta = dmin(2.0, dmax(zeta, 0.01));
   } else {
-    zeta = rib * log(zldis / z0m);
+    zeta = rib * elmk_log(zldis / z0m);
     zeta = dmax(-100.0, dmin(zeta, -0.01));
   }
   obu = zldis / zeta;
@@ -289,13 +290,13 @@ __device__ __forceinline__ double fv_wind(double forc_hgt_u, double displa, doub
   const double zeta = zldis / obu;
   if (zeta < (-zetam)) {
     return VKC * um /
-           (log(-zetam * obu / z0m) - stab1(-zetam) + stab1(z0m / obu) + 1.14 * (pow((-zeta), 0.333) - pow(zetam, 0.333)));
+           (elmk_log(-zetam * obu / z0m) - stab1(-zetam) + stab1(z0m / obu) + 1.14 * (elmk_pow((-zeta), 0.333) - elmk_pow(zetam, 0.333)));
   } else if (zeta < 0.0) {
-    return VKC * um / (log(zldis / z0m) - stab1(zeta) + stab1(z0m / obu));
+    return VKC * um / (elmk_log(zldis / z0m) - stab1(zeta) + stab1(z0m / obu));
   } else if (zeta <= 1.0) {
-    return VKC * um / (log(zldis / z0m) + 5.0 * zeta - 5.0 * z0m / obu);
+    return VKC * um / (elmk_log(zldis / z0m) + 5.0 * zeta - 5.0 * z0m / obu);
   }
-  return VKC * um / (log(obu / z0m) + 5.0 - 5.0 * z0m / obu + (5.0 * log(zeta) + zeta - 1.0));
+  return VKC * um / (elmk_log(obu / z0m) + 5.0 - 5.0 * z0m / obu + (5.0 * elmk_log(zeta) + zeta - 1.0));
 }
 
 // the temperature/humidity profile relation shared by :86-172 (zetat = 0.465); GROUPED selects the
@@ -306,14 +307,14 @@ __device__ __forceinline__ double fv_profile(double zldis, double obu, double z0
   const double zetat = 0.465;
   const double zeta = zldis / obu;
   if (zeta < -zetat) {
-    return VKC / (log(-zetat * obu / z0) - stab2(-zetat) + stab2(z0 / obu) + 0.8 * (pow(zetat, -0.333) - pow((-zeta), -0.333)));
+    return VKC / (elmk_log(-zetat * obu / z0) - stab2(-zetat) + stab2(z0 / obu) + 0.8 * (elmk_pow(zetat, -0.333) - elmk_pow((-zeta), -0.333)));
   } else if (zeta < 0.0) {
-    return VKC / (log(zldis / z0) - stab2(zeta) + stab2(z0 / obu));
+    return VKC / (elmk_log(zldis / z0) - stab2(zeta) + stab2(z0 / obu));
   } else if (zeta <= 1.0) {
-    return VKC / (log(zldis / z0) + 5.0 * zeta - 5.0 * z0 / obu);
+    return VKC / (elmk_log(zldis / z0) + 5.0 * zeta - 5.0 * z0 / obu);
   }
-  if (GROUPED) return VKC / (log(obu / z0) + 5.0 - 5.0 * (z0 / obu) + (5.0 * log(zeta) + zeta - 1.0));
-  return VKC / (log(obu / z0) + 5.0 - 5.0 * z0 / obu + (5.0 * log(zeta) + zeta - 1.0));
+  if (GROUPED) return VKC / (elmk_log(obu / z0) + 5.0 - 5.0 * (z0 / obu) + (5.0 * elmk_log(zeta) + zeta - 1.0));
+  return VKC / (elmk_log(obu / z0) + 5.0 - 5.0 * z0 / obu + (5.0 * elmk_log(zeta) + zeta - 1.0));
 }
 
 // stab1(x) and stab2(x) of the same argument: stab2(x) is twice the second logarithm of stab1(x) (:17-33)
@@ -321,8 +322,8 @@ __device__ __forceinline__ void stab12(double zeta, double& s1, double& s2)
 {
   const double chik2 = sqrt(1.0 - 16.0 * zeta);
   const double chik = sqrt(chik2);
-  const double lg2 = log((1.0 + chik2) * 0.5);
-  s1 = 2.0 * log((1.0 + chik) * 0.5) + lg2 - 2.0 * atan(chik) + ELM_PI * 0.5;
+  const double lg2 = elmk_log((1.0 + chik2) * 0.5);
+  s1 = 2.0 * elmk_log((1.0 + chik) * 0.5) + lg2 - 2.0 * elmk_atan(chik) + ELM_PI * 0.5;
   s2 = 2.0 * lg2;
 }
 
@@ -333,8 +334,8 @@ struct FvConst {
 __device__ __forceinline__ FvConst fv_const()
 {
   FvConst k;
-  k.pw_m = pow(1.574, 0.333);
-  k.pw_t = pow(0.465, -0.333);
+  k.pw_m = elmk_pow(1.574, 0.333);
+  k.pw_t = elmk_pow(0.465, -0.333);
   return k;
 }
 
@@ -369,11 +370,11 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   const double au = u1 ? (-zetam * obu / z0m) : ((u2 || u3) ? (zl_u / z0m) : (obu / z0m));
   const double at = t1 ? (-zetat * obu / z0h) : ((t2 || t3) ? (zl_t / z0h) : (obu / z0h));
   const double a2 = b1 ? (-zetat * obu / z0h) : ((b2 || b3) ? (zl_2 / z0h) : (obu / z0h));
-  const double Lu = log(au);
+  const double Lu = elmk_log(au);
   double Lt = Lu;
-  if (!(at == au)) Lt = log(at);
+  if (!(at == au)) Lt = elmk_log(at);
   double L2 = Lt;
-  if (WITH_2M && !(a2 == at)) L2 = log(a2);
+  if (WITH_2M && !(a2 == at)) L2 = elmk_log(a2);
 
   double su = 0.0, st = 0.0, s2 = 0.0, sz1 = 0.0, sz2 = 0.0;
   if (u1 || u2 || t1 || t2 || b1 || b2) {
@@ -392,18 +393,18 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   }
   double pu = 0.0, pt = 0.0, p2 = 0.0;
   if (u1 || t1 || b1) {
-    if (u1) pu = pow((-ze_u), 0.333);
-    if (t1) pt = pow((-ze_t), -0.333);
+    if (u1) pu = elmk_pow((-ze_u), 0.333);
+    if (t1) pt = elmk_pow((-ze_t), -0.333);
     p2 = pt;
-    if (b1 && !(ze_2 == ze_t && t1)) p2 = pow((-ze_2), -0.333);
+    if (b1 && !(ze_2 == ze_t && t1)) p2 = elmk_pow((-ze_2), -0.333);
   }
   const bool u4 = !u1 && !u2 && !u3, t4 = !t1 && !t2 && !t3, b4 = !b1 && !b2 && !b3;
   double lu = 0.0, lt = 0.0, l2 = 0.0;
   if (u4 || t4 || b4) {
-    if (u4) lu = log(ze_u);
+    if (u4) lu = elmk_log(ze_u);
     lt = lu;
-    if (t4 && !(ze_t == ze_u && u4)) lt = log(ze_t);
-    if (b4) l2 = log(ze_2);
+    if (t4 && !(ze_t == ze_u && u4)) lt = elmk_log(ze_t);
+    if (b4) l2 = elmk_log(ze_2);
   }
 
   double du, dt, d2;

@@ -1,0 +1,414 @@
+// elmk_math.h - exp / log / pow / log10 that return the bits of the host libm the reference runs on.
+//
+// Why this exists.  The reference's physics calls <cmath>; on the platform it is built and tested on (x86-64 Linux, glibc)
+// exp, log and pow are Szabolcs Nagy's table-driven routines (glibc >= 2.28: sysdeps/ieee754/dbl-64/e_exp.c, e_log.c,
+// e_pow.c; the same code is published as ARM optimized-routines math/exp.c, log.c, pow.c).  They are accurate to about
+// 0.51 ulp, i.e. NOT correctly rounded, and the device libm (ocml) rounds a few per cent of arguments the other way.  The
+// leaf-temperature iteration of canopy_fluxes contains tolerance-terminated root finds, so one differing last bit can
+// change an inner trip count and move an output by 1e-8 relative - far outside the north star's 1e-12.  Restating the
+// host algorithm on the device removes the cause instead of widening the tolerance: same tables
+// (elmk_math_tables.h), same operation sequence, same fused multiply-adds.
+//
+// The operation sequence - in particular WHICH a*b+c are fused - is the one of the x86-64 FMA build of glibc 2.35
+// (__exp_fma / __log_fma / __pow_fma, selected at run time on every CPU with FMA + AVX2; read from the disassembly of the
+// image's libm.so.6, Ubuntu GLIBC 2.35-0ubuntu3.11).  Every fused operation below is an explicit fma(); the file must be
+// compiled with -ffp-contract=off so that nothing else is fused.  log10 is glibc's e_log10.c (a scaling around log()),
+// which has no FMA build: plain multiplies and adds.
+//
+// The same header compiles for the host with gcc (tests/test_math_host.py compares it with the live libm on 10^8
+// arguments, bit for bit) and for the device with hipcc (tests/test_gpu_parity.py::test_device_math_bits).
+// No errno, no floating-point exception flags; results (including inf / nan / subnormal) are identical.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ELMK_MFN __device__ __forceinline__
+#define ELMK_MFN_NOINLINE __device__ __noinline__
+#define ELMK_MATH_TABLE static __device__ const uint64_t
+#else
+#define ELMK_MFN static inline
+#define ELMK_MFN_NOINLINE static
+#define ELMK_MATH_TABLE static const uint64_t
+#endif
+#include "elmk_math_tables.h"
+
+ELMK_MFN uint64_t elmk_asu64(double x)
+{
+  union { double f; uint64_t i; } u;
+  u.f = x;
+  return u.i;
+}
+ELMK_MFN double elmk_asf64(uint64_t i)
+{
+  union { double f; uint64_t i; } u;
+  u.i = i;
+  return u.f;
+}
+#define ELMK_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define ELMK_INF elmk_asf64(0x7ff0000000000000ull)
+#define ELMK_NAN elmk_asf64(0x7ff8000000000000ull)
+
+// ---- 2^(k/128)·(1 + tmp): shared tail of exp and pow (e_exp.c / e_pow.c "specialcase" included) ----------------------
+// tmp = tail + r + r^2 (C2 + r C3) + r^4 (C4 + r C5), fused exactly as the FMA build does
+ELMK_MFN double elmk_exp_poly(double r, double tail)
+{
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  const double p23 = ELMK_FMA(r, C3, C2);
+  const double tr = tail + r;
+  const double r2 = r * r;
+  const double p45 = ELMK_FMA(r, C5, C4);
+  const double lo = ELMK_FMA(p23, r2, tr);
+  const double r4 = r2 * r2;
+  return ELMK_FMA(r4, p45, lo);
+}
+
+// result would over/underflow the normal range: e_exp.c specialcase() / e_pow.c specialcase() (the latter handles a signed
+// scale; with sbits >= 0 the two are the same function)
+ELMK_MFN double elmk_exp_special(double tmp, uint64_t sbits, uint64_t ki)
+{
+  if ((ki & 0x80000000ull) == 0) {  // k > 0: the exponent of scale might have overflowed by <= 460
+    sbits -= 1009ull << 52;
+    const double scale = elmk_asf64(sbits);
+    return 0x1p1009 * ELMK_FMA(scale, tmp, scale);
+  }
+  sbits += 1022ull << 52;  // k < 0: care in the subnormal range
+  const double scale = elmk_asf64(sbits);
+  const double st = scale * tmp;
+  double y = scale + st;
+  if (__builtin_fabs(y) < 1.0) {
+    const double one = (y < 0.0) ? -1.0 : 1.0;
+    double lo = scale - y + st;
+    const double hi = one + y;
+    lo = one - hi + y + lo;
+    y = (hi + lo) - one;
+    if (y == 0.0) y = elmk_asf64(sbits & 0x8000000000000000ull);
+  }
+  return 0x1p-1022 * y;
+}
+
+// exp(x + xtail) with the sign of the result flipped when sign_bias != 0 (e_pow.c exp_inline); exp(x) = (x, 0, 0) except
+// for the two differences noted at elmk_exp
+ELMK_MFN double elmk_exp_core(double x, double xtail, uint32_t sign_bias, int with_tail)
+{
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  uint32_t abstop = (uint32_t)(elmk_asu64(x) >> 52) & 0x7ff;
+  if (abstop - 0x3c9u >= 0x3fu) {  // |x| < 2^-54 or |x| >= 512
+    if (abstop - 0x3c9u >= 0x80000000u) {
+      const double one = 1.0 + x;
+      return sign_bias ? -one : one;
+    }
+    if (abstop >= 0x409u) {  // |x| >= 1024 (inf and nan are handled by the callers)
+      if (elmk_asu64(x) >> 63) return sign_bias ? -0.0 : 0.0;  // __math_uflow
+      return sign_bias ? -ELMK_INF : ELMK_INF;                 // __math_oflow
+    }
+    abstop = 0;  // large x: special-cased below
+  }
+  double kd = ELMK_FMA(x, InvLn2N, Shift);
+  const uint64_t ki = elmk_asu64(kd);
+  kd -= Shift;
+  double r = ELMK_FMA(kd, NegLn2hiN, x);
+  r = ELMK_FMA(kd, NegLn2loN, r);
+  if (with_tail) r = xtail + r;
+  const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+  const uint64_t top = (ki + sign_bias) << 45;
+  const double tail = elmk_asf64(elmk_exp_tab[idx]);
+  const uint64_t sbits = elmk_exp_tab[idx + 1] + top;
+  const double tmp = elmk_exp_poly(r, tail);
+  if (abstop == 0) return elmk_exp_special(tmp, sbits, ki);
+  const double scale = elmk_asf64(sbits);
+  return ELMK_FMA(scale, tmp, scale);
+}
+
+// ---- exp: glibc 2.35 sysdeps/ieee754/dbl-64/e_exp.c (__exp_fma) -------------------------------------------------------
+ELMK_MFN double elmk_exp(double x)
+{
+  const uint64_t ix = elmk_asu64(x);
+  const uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ff;
+  if (abstop >= 0x409u) {  // |x| >= 1024, inf, nan: the cases exp_inline leaves to its caller
+    if (ix == 0xfff0000000000000ull) return 0.0;
+    if (abstop >= 0x7ffu) return 1.0 + x;
+    return (ix >> 63) ? 0.0 : ELMK_INF;
+  }
+  return elmk_exp_core(x, 0.0, 0, 0);
+}
+
+// ---- log: glibc 2.35 sysdeps/ieee754/dbl-64/e_log.c (__log_fma) -------------------------------------------------------
+ELMK_MFN double elmk_log(double x)
+{
+  uint64_t ix = elmk_asu64(x);
+  const uint32_t top = (uint32_t)(ix >> 48);
+  if (ix - 0x3fee000000000000ull < 0x3090000000000ull) {  // 1 - 2^-4 <= x < 1 + 0x1.09p-4
+    if (ix == 0x3ff0000000000000ull) return 0.0;
+    const double B0 = -0x1p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3,
+                 B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de3p-3, B6 = -0x1.fffffa4423d65p-4,
+                 B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4, B9 = 0x1.78182f7afd085p-4,
+                 B10 = -0x1.5521375d145cdp-4;
+    const double r = x - 1.0;
+    double p1 = ELMK_FMA(r, B2, B1);
+    double p4 = ELMK_FMA(r, B5, B4);
+    const double r2 = r * r;
+    double p7 = ELMK_FMA(r, B8, B7);
+    p1 = ELMK_FMA(r2, B3, p1);
+    p4 = ELMK_FMA(r2, B6, p4);
+    const double r3 = r * r2;
+    p7 = ELMK_FMA(r2, B9, p7);
+    p7 = ELMK_FMA(r3, B10, p7);
+    p4 = ELMK_FMA(p7, r3, p4);
+    p1 = ELMK_FMA(p4, r3, p1);
+    const double t = ELMK_FMA(r, 0x1p27, r);
+    const double rhi = ELMK_FMA(-0x1p27, r, t);
+    const double rhi2 = rhi * rhi;
+    const double rlo = r - rhi;
+    const double hi = ELMK_FMA(rhi2, B0, r);
+    const double t8 = r - hi;
+    const double s = r + rhi;
+    double lo = ELMK_FMA(rhi2, B0, t8);
+    const double u = B0 * rlo;
+    lo = ELMK_FMA(u, s, lo);
+    const double y = ELMK_FMA(p1, r3, lo);
+    return hi + y;
+  }
+  if (top - 0x0010u >= 0x7ff0u - 0x0010u) {  // x < 2^-1022, inf or nan
+    if (ix * 2 == 0) return -ELMK_INF;
+    if (ix == 0x7ff0000000000000ull) return x;
+    if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) return (x != x) ? x + x : ELMK_NAN;  // __math_invalid
+    ix = elmk_asu64(x * 0x1p52);  // subnormal: normalise
+    ix -= 52ull << 52;
+  }
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb459p-3, A3 = 0x1.999b324f10111p-3,
+               A4 = -0x1.55575e506c89fp-3;
+  const uint64_t tmp = ix - 0x3fe6000000000000ull;
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+  const int k = (int)((int64_t)tmp >> 52);
+  const uint64_t iz = ix - (tmp & 0xfffull << 52);
+  const double invc = elmk_asf64(elmk_log_tab[2 * i]), logc = elmk_asf64(elmk_log_tab[2 * i + 1]);
+  const double z = elmk_asf64(iz);
+  const double kd = (double)k;
+  const double r = ELMK_FMA(z, invc, -1.0);
+  const double w = ELMK_FMA(kd, Ln2hi, logc);
+  const double p12 = ELMK_FMA(r, A2, A1);
+  const double hi = w + r;
+  const double r2 = r * r;
+  double lo = w - hi;
+  lo = lo + r;
+  lo = ELMK_FMA(kd, Ln2lo, lo);
+  const double r3 = r * r2;
+  double p34 = ELMK_FMA(r, A4, A3);
+  lo = ELMK_FMA(r2, A0, lo);
+  p34 = ELMK_FMA(p34, r2, p12);
+  const double y = ELMK_FMA(r3, p34, lo);
+  return y + hi;
+}
+
+// ---- log10: glibc 2.35 sysdeps/ieee754/dbl-64/e_log10.c (fdlibm scaling around __ieee754_log; no FMA build) ------------
+ELMK_MFN double elmk_log10(double x)
+{
+  const double two54 = 1.80143985094819840000e+16, ivln10 = 4.34294481903251816668e-01,
+               log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+  uint64_t ix = elmk_asu64(x);
+  int32_t hx = (int32_t)(ix >> 32);
+  const uint32_t lx = (uint32_t)ix;
+  int32_t k = 0;
+  if (hx < 0x00100000) {  // x < 2^-1022
+    if (((hx & 0x7fffffff) | lx) == 0) return -ELMK_INF;
+    if (hx < 0) return (x != x) ? x + x : ELMK_NAN;
+    k -= 54;
+    x *= two54;
+    ix = elmk_asu64(x);
+    hx = (int32_t)(ix >> 32);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  const int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x000fffff) | ((0x3ff - i) << 20);
+  const double y = (double)(k + i);
+  x = elmk_asf64(((uint64_t)(uint32_t)hx << 32) | (elmk_asu64(x) & 0xffffffffull));
+  const double z = y * log10_2lo + ivln10 * elmk_log(x);
+  return z + y * log10_2hi;
+}
+
+// ---- pow: glibc 2.35 sysdeps/ieee754/dbl-64/e_pow.c (__pow_fma) -------------------------------------------------------
+// 0: y is not an integer, 1: odd integer, 2: even integer
+ELMK_MFN int elmk_checkint(uint64_t iy)
+{
+  const int e = (int)(iy >> 52) & 0x7ff;
+  if (e < 0x3ff) return 0;
+  if (e > 0x3ff + 52) return 2;
+  if (iy & ((1ull << (0x3ff + 52 - e)) - 1)) return 0;
+  if (iy & (1ull << (0x3ff + 52 - e))) return 1;
+  return 2;
+}
+ELMK_MFN int elmk_zeroinfnan(uint64_t i) { return 2 * i - 1 >= 2 * 0x7ff0000000000000ull - 1; }
+
+ELMK_MFN double elmk_pow(double x, double y)
+{
+  uint32_t sign_bias = 0;
+  uint64_t ix = elmk_asu64(x);
+  const uint64_t iy = elmk_asu64(y);
+  uint32_t topx = (uint32_t)(ix >> 52);
+  const uint32_t topy = (uint32_t)(iy >> 52);
+  if (topx - 0x001u >= 0x7ffu - 0x001u || (topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu) {
+    // x < 2^-1022, inf or nan; or |y| < 2^-65, |y| >= 2^63 or nan
+    if (elmk_zeroinfnan(iy)) {
+      if (2 * iy == 0) return 1.0;
+      if (ix == 0x3ff0000000000000ull) return 1.0;
+      if (2 * ix > 2 * 0x7ff0000000000000ull || 2 * iy > 2 * 0x7ff0000000000000ull) return x + y;
+      if (2 * ix == 2 * 0x3ff0000000000000ull) return 1.0;
+      if ((2 * ix < 2 * 0x3ff0000000000000ull) == !(iy >> 63)) return 0.0;  // |x|<1 && y==inf or |x|>1 && y==-inf
+      return y * y;
+    }
+    if (elmk_zeroinfnan(ix)) {
+      double x2 = x * x;
+      if ((ix >> 63) && elmk_checkint(iy) == 1) x2 = -x2;
+      return (iy >> 63) ? 1.0 / x2 : x2;
+    }
+    if (ix >> 63) {  // finite x < 0
+      const int yint = elmk_checkint(iy);
+      if (yint == 0) return ELMK_NAN;  // __math_invalid
+      if (yint == 1) sign_bias = 0x800u << 7;
+      ix &= 0x7fffffffffffffffull;
+      topx &= 0x7ffu;
+    }
+    if ((topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu) {
+      if (ix == 0x3ff0000000000000ull) return 1.0;
+      if ((topy & 0x7ffu) < 0x3beu) return ix > 0x3ff0000000000000ull ? 1.0 + y : 1.0 - y;  // |y| < 2^-65
+      return ((ix > 0x3ff0000000000000ull) == (topy < 0x800u)) ? ELMK_INF : 0.0;
+    }
+    if (topx == 0) {  // subnormal x: normalise
+      ix = elmk_asu64(x * 0x1p52);
+      ix &= 0x7fffffffffffffffull;
+      ix -= 52ull << 52;
+    }
+  }
+  // log_inline: log(x) = hi + lo to ~68 bits
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A0 = -0x1p-1, A1 = -0x1.555555555556p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
+               A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p0, A6 = 0x1.0002b8b263fc3p0;
+  const uint64_t tmp = ix - 0x3fe6955500000000ull;
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+  const int k = (int)((int64_t)tmp >> 52);
+  const uint64_t iz = ix - (tmp & 0xfffull << 52);
+  const double z = elmk_asf64(iz);
+  const double kd = (double)k;
+  const double invc = elmk_asf64(elmk_powlog_tab[3 * i]), logc = elmk_asf64(elmk_powlog_tab[3 * i + 1]),
+               logctail = elmk_asf64(elmk_powlog_tab[3 * i + 2]);
+  const double r = ELMK_FMA(z, invc, -1.0);
+  const double t1 = ELMK_FMA(kd, Ln2hi, logc);
+  const double t2 = t1 + r;
+  const double lo1 = ELMK_FMA(kd, Ln2lo, logctail);
+  const double lo2 = t1 - t2 + r;
+  const double ar = A0 * r;
+  const double ar2 = r * ar;
+  const double ar3 = r * ar2;
+  const double hi = t2 + ar2;
+  const double lo3 = ELMK_FMA(ar, r, -ar2);
+  const double lo4 = t2 - hi + ar2;
+  const double p12 = ELMK_FMA(r, A2, A1);
+  const double p34 = ELMK_FMA(r, A4, A3);
+  double p = ELMK_FMA(r, A6, A5);
+  p = ELMK_FMA(p, ar2, p34);
+  p = ELMK_FMA(ar2, p, p12);
+  double lo = lo1 + lo2;
+  lo = lo + lo3;
+  lo = lo + lo4;
+  lo = ELMK_FMA(p, ar3, lo);
+  const double lhi = hi + lo;
+  const double llo = hi - lhi + lo;
+  // y·log(x) = ehi + elo
+  const double ehi = y * lhi;
+  double elo = ELMK_FMA(lhi, y, -ehi);
+  elo = ELMK_FMA(y, llo, elo);
+  return elmk_exp_core(ehi, elo, sign_bias, 1);
+}
+
+// ---- atan: glibc 2.35 sysdeps/ieee754/dbl-64/s_atan.c (__atan_fma; IBM Accurate Mathematical Library, the version with
+// the multi-precision fall-backs removed) --------------------------------------------------------------------------------
+ELMK_MFN double elmk_atan_signed(double y, double x)  // |y| with the sign of x
+{
+  return elmk_asf64((elmk_asu64(y) & 0x7fffffffffffffffull) | (elmk_asu64(x) & 0x8000000000000000ull));
+}
+ELMK_MFN double elmk_atan(double x)
+{
+  const double d3 = -0x1.5555555555555p-2, d5 = 0x1.99999999997fdp-3, d7 = -0x1.24924923f7603p-3, d9 = 0x1.c71c6e5129a3bp-4,
+               d11 = -0x1.7458022b13c25p-4, d13 = 0x1.375f08b31cbcep-4;
+  const double HPI = 0x1.921fb54442d18p+0, HPI1 = 0x1.1a62633145c07p-54;
+  const uint64_t ix = elmk_asu64(x);
+  if ((ix & 0x7ff0000000000000ull) == 0x7ff0000000000000ull && (ix & 0x000fffffffffffffull) != 0) return x + x;  // nan
+  const double u = (x < 0.0) ? -x : x;
+  if (u < 1.0) {
+    if (u < 0x1p-4) {
+      if (u < 0x1.bb67ap-27) return x;
+      const double v = x * x;
+      double p = d13;
+      p = ELMK_FMA(v, p, d11);
+      p = ELMK_FMA(v, p, d9);
+      p = ELMK_FMA(v, p, d7);
+      p = ELMK_FMA(v, p, d5);
+      p = ELMK_FMA(v, p, d3);
+      return ELMK_FMA(x * v, p, x);
+    }
+    const int i = (int)(ELMK_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
+    const uint64_t* c = elmk_atan_tab + 7 * i;
+    const double z = u - elmk_asf64(c[0]);
+    double p = elmk_asf64(c[6]);
+    p = ELMK_FMA(z, p, elmk_asf64(c[5]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[4]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[3]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[2]));
+    return elmk_atan_signed(ELMK_FMA(p, z, elmk_asf64(c[1])), x);
+  }
+  if (u < 16.0) {
+    const double w = 1.0 / u;
+    const double t1 = u * w;
+    const double a = 1.0 - t1;
+    const double t2 = ELMK_FMA(u, w, -t1);
+    const int i = (int)(ELMK_FMA(w, 256.0, 0x1p52) - 0x1p52) - 16;
+    const uint64_t* c = elmk_atan_tab + 7 * i;
+    const double t3 = a - t2;
+    const double zz = w - elmk_asf64(c[0]);
+    const double z = ELMK_FMA(t3, w, zz);
+    double p = elmk_asf64(c[6]);
+    p = ELMK_FMA(z, p, elmk_asf64(c[5]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[4]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[3]));
+    p = ELMK_FMA(z, p, elmk_asf64(c[2]));
+    const double yy = ELMK_FMA(-z, p, HPI1);
+    const double t = HPI - elmk_asf64(c[1]);
+    return elmk_atan_signed(t + yy, x);
+  }
+  if (u < 0x1.49ff2p+52) {
+    const double w = 1.0 / u;
+    const double v = w * w;
+    const double t1 = u * w;
+    double p = d13;
+    p = ELMK_FMA(v, p, d11);
+    p = ELMK_FMA(v, p, d9);
+    p = ELMK_FMA(v, p, d7);
+    p = ELMK_FMA(v, p, d5);
+    p = ELMK_FMA(v, p, d3);
+    const double wv = w * v;
+    const double t2 = ELMK_FMA(u, w, -t1);
+    double a = 1.0 - t1;
+    const double yy = wv * p;
+    a = a - t2;
+    const double t3 = HPI - w;
+    const double ww = a * w;
+    const double cor = (HPI - t3) - w;
+    double r = cor + HPI1;
+    r = r - ww;
+    r = r - yy;
+    return elmk_atan_signed(r + t3, x);
+  }
+  return (x > 0.0) ? HPI : -HPI;
+}
+
+// ---- pow(x, 2.0) and pow(x, 1.0) as the reference's COMPILER evaluates them ---------------------------------------------
+// GCC replaces pow(x, 2.0) / std::pow(x, 2) by x * x at -O1 and above and pow(x, 1.0) by x at every level, without
+// -ffast-math (checked with the image's gcc 11.4: `mulsd %xmm0, %xmm0`, no call).  The oracle and oracle/_ref (the
+// reference's own headers) are -O2 builds, so that is what "the reference's result" is at these call sites; glibc's
+// pow(x, 2.0) itself rounds the other way for a small fraction of arguments (it is a 0.52 ulp routine), which is what the
+// reference's default Debug (-O0) build would return.
+ELMK_MFN double elmk_sq(double x) { return x * x; }
+ELMK_MFN double elmk_pow1(double x) { return x; }

@@ -148,8 +148,8 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
       const double omega = (1.0 / tau) * (omega_sum + (ss_snw * tau_snw));
       const double g = (1.0 / (tau * omega)) * (g_sum + (asm_snw * ss_snw * tau_snw));
       g_star[i] = g / (1.0 + g);
-      omega_star[i] = ((1.0 - pow(g, 2.0)) * omega) / (1.0 - (omega * pow(g, 2.0)));
-      tau_star[i] = (1.0 - (omega * pow(g, 2.0))) * tau;
+      omega_star[i] = ((1.0 - elmk_sq(g)) * omega) / (1.0 - (omega * elmk_sq(g)));
+      tau_star[i] = (1.0 - (omega * elmk_sq(g))) * tau;
     }
   }
 
@@ -183,11 +183,11 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
         const double gs = g_star[i];
         const double lm = sqrt(c3 * (c1 - ws) * (c1 - ws * gs));
         const double ue = c1p5 * (c1 - ws * gs) / lm;
-        const double extins = dmax(SN_EXP_MIN, exp(-lm * ts));
+        const double extins = dmax(SN_EXP_MIN, elmk_exp(-lm * ts));
         const double ne = ((ue + c1) * (ue + c1) / extins) - ((ue - c1) * (ue - c1) * extins);
-        const double R1 = (pow(ue, 2.0) - c1) * (c1 / extins - extins) / ne;
+        const double R1 = (elmk_sq(ue) - c1) * (c1 / extins - extins) / ne;
         const double T1 = c4 * ue / ne;
-        trnlay[i] = dmax(SN_EXP_MIN, exp(-ts / mu_not));
+        trnlay[i] = dmax(SN_EXP_MIN, elmk_exp(-ts / mu_not));
         double alp = cp75 * ws * mu_not * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu_not * mu_not));
         double gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu_not * mu_not) / (c1 - lm * lm * mu_not * mu_not));
         double apg = alp + gam;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
           const double mu = difgauspt[ng];
           const double gwt = difgauswt[ng];
           swt = swt + mu * gwt;
-          const double trn = dmax(SN_EXP_MIN, exp(-ts / mu));
+          const double trn = dmax(SN_EXP_MIN, elmk_exp(-ts / mu));
           alp = cp75 * ws * mu * ((c1 + gs * (c1 - ws)) / (c1 - lm * lm * mu * mu));
           gam = cp5 * ws * ((c1 + c3 * gs * (c1 - ws) * mu * mu) / (c1 - lm * lm * mu * mu));
           apg = alp + gam;
@@ -334,9 +334,9 @@ __device__ __forceinline__ void snicar_combine(const int g0, const int pass, con
   }
   // near-IR direct albedo/absorption adjustment at high solar zenith angle (:748-757)
   if (pass == 0 && mu_not < 0.2588) {
-    const double sza_c1 = 0.085730 + (-0.630883) * mu_not + 1.303723 * pow(mu_not, 2.0);
-    const double sza_c0 = 1.467291 + (-3.338043) * mu_not + 6.807489 * pow(mu_not, 2.0);
-    const double sza_factor = sza_c1 * (log10(rds_top * 1.0) - 6.0) + sza_c0;
+    const double sza_c1 = 0.085730 + (-0.630883) * mu_not + 1.303723 * elmk_sq(mu_not);
+    const double sza_c0 = 1.467291 + (-3.338043) * mu_not + 6.807489 * elmk_sq(mu_not);
+    const double sza_factor = sza_c1 * (elmk_log10(rds_top * 1.0) - 6.0) + sza_c0;
     const double flx_sza_adjust = out.alb[1] * (sza_factor - 1.0) * wgt_sum;
     out.alb[1] *= sza_factor;
     out.fabs_[snl_top][1] -= flx_sza_adjust;
@@ -387,7 +387,7 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
       }
     } else if (L.ltype == istdlak && snl == 0) {
       const double t_grnd = S->t_grnd[c];
-      const double sicefr = 1.0 - exp(-95.6 * (TFRZ - t_grnd) / TFRZ);
+      const double sicefr = 1.0 - elmk_exp(-95.6 * (TFRZ - t_grnd) / TFRZ);
 #pragma unroll
       for (int ib = 0; ib < 2; ib++) {
         albsod[ib] = sicefr * alblak[ib] + (1.0 - sicefr) * dmax(alblakwi[ib], 0.05 / (dmax(0.001, coszen) + 0.15));
@@ -470,10 +470,10 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
     const double phi2 = 0.877 * (1.0 - 2.0 * phi1);
     const double gdir = phi1 + phi2 * cosz;
     const double twostext = gdir / cosz;
-    const double avmu = (1.0 - phi1 / phi2 * log((phi1 + phi2) / phi1)) / phi2;
+    const double avmu = (1.0 - phi1 / phi2 * elmk_log((phi1 + phi2) / phi1)) / phi2;
     const double temp0 = gdir + phi2 * cosz;
     const double temp1 = phi1 * cosz;
-    const double temp2 = (1.0 - temp1 / temp0 * log((temp1 + temp0) / temp1));
+    const double temp2 = (1.0 - temp1 / temp0 * elmk_log((temp1 + temp0) / temp1));
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {
       const double rho = dmax(A[0 + ib] * wl + A[2 + ib] * ws, SA_MPE);
@@ -481,7 +481,7 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
       const double omegal = rho + tau;
       const double asu = 0.5 * omegal * gdir / temp0 * temp2;
       const double betadl = (1.0 + avmu * twostext) / (omegal * avmu * twostext) * asu;
-      const double betail = 0.5 * ((rho + tau) + (rho - tau) * pow(((1.0 + chil) / 2.0), 2.0)) / omegal;
+      const double betail = 0.5 * ((rho + tau) + (rho - tau) * elmk_sq(((1.0 + chil) / 2.0))) / omegal;
       double tmp0, tmp1, tmp2;
       if (t_veg > TFRZ) {
         tmp0 = omegal;
@@ -508,9 +508,9 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
       const double p3 = b + tmp0;
       const double p4 = b - tmp0;
       double t1 = dmin(h * (elai + esai), 40.0);
-      const double s1 = exp(-t1);
+      const double s1 = elmk_exp(-t1);
       t1 = dmin(twostext * (elai + esai), 40.0);
-      const double s2 = exp(-t1);
+      const double s2 = elmk_exp(-t1);
       // direct beam
       double u1 = b - c1 / albgrd[ib];
       double u2 = b - c1 * albgrd[ib];
@@ -569,8 +569,8 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
         fabd_sha_z = fabd_sha / ((1.0 - fsun_z) * laisum);
         fabi_sha_z = fabi_sha[ib] / ((1.0 - fsun_z) * laisum);
         const double extkb = twostext;
-        vcmaxcintsun = (1.0 - exp(-(SA_EXTKN + extkb) * elai)) / (SA_EXTKN + extkb);
-        vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN - vcmaxcintsun;
+        vcmaxcintsun = (1.0 - elmk_exp(-(SA_EXTKN + extkb) * elai)) / (SA_EXTKN + extkb);
+        vcmaxcintsha = (1.0 - elmk_exp(-SA_EXTKN * elai)) / SA_EXTKN - vcmaxcintsun;
         if (elai > 0.0) {
           vcmaxcintsun = vcmaxcintsun / (fsun_z * elai);
           vcmaxcintsha = vcmaxcintsha / ((1.0 - fsun_z) * elai);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
   const double elai = S->elai[c];
   // init_timestep values of the leaf-to-canopy scaling coefficients (overwritten by two_stream where vegetated)
   double vcmaxcintsun = 0.0;
-  double vcmaxcintsha = (1.0 - exp(-SA_EXTKN * elai)) / SA_EXTKN;
+  double vcmaxcintsha = (1.0 - elmk_exp(-SA_EXTKN * elai)) / SA_EXTKN;
   if (elai > 0.0) {
     vcmaxcintsha /= elai;
   } else {

@@ -27,15 +27,15 @@ namespace elmk {
 // photosynthesis_impl.hh:623-635
 __device__ __forceinline__ double psn_ft(double tl, double ha)
 {
-  return exp(ha / (RGAS * 1.0e-3 * (TFRZ + 25.0)) * (1.0 - (TFRZ + 25.0) / tl));
+  return elmk_exp(ha / (RGAS * 1.0e-3 * (TFRZ + 25.0)) * (1.0 - (TFRZ + 25.0) / tl));
 }
 __device__ __forceinline__ double psn_fth(double tl, double hd, double se, double scaleFactor)
 {
-  return scaleFactor / (1.0 + exp((-hd + se * tl) / (RGAS * 1.0e-3 * tl)));
+  return scaleFactor / (1.0 + elmk_exp((-hd + se * tl) / (RGAS * 1.0e-3 * tl)));
 }
 __device__ __forceinline__ double psn_fth25(double hd, double se)
 {
-  return 1.0 + exp((-hd + se * (TFRZ + 25.0)) / (RGAS * 1.0e-3 * (TFRZ + 25.0)));
+  return 1.0 + elmk_exp((-hd + se * (TFRZ + 25.0)) / (RGAS * 1.0e-3 * (TFRZ + 25.0)));
 }
 
 // photosynthesis_impl.hh:286-302
@@ -243,16 +243,16 @@ __device__ __forceinline__ PsnTemp psn_temp(const PsnInv& I, const double* __res
     T.ft_lmr = psn_ft(t_veg, P[P_lmrha]);
     T.fth_lmr = psn_fth(t_veg, P[P_lmrhd], P[P_lmrse], I.lmrc);
   } else {
-    T.p2 = pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
-    T.e_lmr_c4 = exp(1.3 * (t_veg - (TFRZ + 55.0)));
+    T.p2 = elmk_pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
+    T.e_lmr_c4 = elmk_exp(1.3 * (t_veg - (TFRZ + 55.0)));
   }
   if (day) {
     if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
       T.ft_vcmax = psn_ft(t_veg, P[P_vcmaxha]);
       T.fth_vcmax = psn_fth(t_veg, P[P_vcmaxhd], I.vcmaxse, I.vcmaxc);
     } else {
-      T.e_vc4a = exp(0.2 * ((TFRZ + 15.0) - t_veg));
-      T.e_vc4b = exp(0.3 * (t_veg - (TFRZ + 40.0)));
+      T.e_vc4a = elmk_exp(0.2 * ((TFRZ + 15.0) - t_veg));
+      T.e_vc4b = elmk_exp(0.3 * (t_veg - (TFRZ + 40.0)));
     }
     T.ft_jmax = psn_ft(t_veg, P[P_jmaxha]);
     T.fth_jmax = psn_fth(t_veg, P[P_jmaxhd], I.jmaxse, I.jmaxc);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
       rootr[i] = 0.0;
     } else {
       const double s_node = dmax(liqvol / eff_por, 0.01);
-      double smp_node = -LV(sucsat, i) * pow(s_node, (-LV(bsw, i)));
+      double smp_node = -LV(sucsat, i) * elmk_pow(s_node, (-LV(bsw, i)));
       smp_node = dmax(smpsc, smp_node);
       const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
       rootr[i] = LV(rootfr, i) * rresis;
@@ -616,11 +616,11 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   PUT(z0mg)
   const double tlsai_crit = 2.0;
   const double lt = dmin(r.elai + r.esai, tlsai_crit);
-  const double egvf = (1.0 - exp(-lt)) / (1.0 - exp(-tlsai_crit));
+  const double egvf = (1.0 - elmk_exp(-lt)) / (1.0 - elmk_exp(-tlsai_crit));
   double displa = S->displa[c];
   displa *= egvf;
   double z0mv = S->z0mv[c];
-  z0mv = exp(egvf * log(z0mv) + (1.0 - egvf) * log(r.z0mg));
+  z0mv = elmk_exp(egvf * elmk_log(z0mv) + (1.0 - egvf) * elmk_log(r.z0mg));
   S->displa[c] = displa;
   S->z0mv[c] = z0mv;
   S->z0hv[c] = z0mv;
@@ -692,13 +692,13 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   }
   PUT(parsun) PUT(parsha) PUT(lai_sun_z) PUT(lai_sha_z)
   // loop-invariant sub-expressions of the iteration body (:272, :301-303, :270)
-  r.w_lai = exp(-(r.elai + r.esai));
+  r.w_lai = elmk_exp(-(r.elai + r.esai));
   PUT(w_lai)
   {
     const double snow_depth_c = 0.05;
     const double fsno_dl = S->snow_depth[c] / snow_depth_c;
     const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
-    r.rdl_num = (1.0 - exp(-elai_dl));
+    r.rdl_num = (1.0 - elmk_exp(-elai_dl));
     PUT(rdl_num)
   }
   r.sqrt_dleaf = sqrt(P[P_dleaf]);
@@ -719,8 +719,8 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 
   // ground-emitted longwave (:366-367), loop-invariant
   const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
-  r.lw_grnd = (frac_sno * pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * pow(t_soi0, 4.0) +
-               frac_h2osfc * pow(S->t_h2osfc[c], 4.0));
+  r.lw_grnd = (frac_sno * elmk_pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * elmk_pow(t_soi0, 4.0) +
+               frac_h2osfc * elmk_pow(S->t_h2osfc[c], 4.0));
   PUT(lw_grnd)
   S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
 
@@ -943,8 +943,8 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double cf = 0.01 / (sqrt(uaf) * in.sqrt_dleaf);
       const double rb = 1.0 / (cf * uaf);
       const double w = in.w_lai;
-      const double csoilb = (VKC / (0.13 * pow((in.z0mg * uaf / 1.5e-5), 0.45)));
-      const double ri = (GRAV * in.htop * (taf - in.t_grnd)) / (taf * pow(uaf, 2.0));
+      const double csoilb = (VKC / (0.13 * elmk_pow((in.z0mg * uaf / 1.5e-5), 0.45)));
+      const double ri = (GRAV * in.htop * (taf - in.t_grnd)) / (taf * elmk_sq(uaf));
       double csoilcn;
       if ((taf - in.t_grnd) > 0.0) {
         const double ricsoilc = CSOILC / (1.0 + 0.5 * dmin(ri, 10.0));
@@ -1034,8 +1034,8 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         efe = 0.1 * efeold;
         erre = efe - efeold;
       }
-      const double tveg3 = pow(t_veg, 3.0);  // t_veg == tlbef here: also the pow(tlbef, 3.0) of errv below (:399)
-      dt_veg = (in.sabv + in.air + in.bir * pow(t_veg, 4.0) + in.cir * in.lw_grnd - efsh - efe) /
+      const double tveg3 = elmk_pow(t_veg, 3.0);  // t_veg == tlbef here: also the pow(tlbef, 3.0) of errv below (:399)
+      dt_veg = (in.sabv + in.air + in.bir * elmk_pow(t_veg, 4.0) + in.cir * in.lw_grnd - efsh - efe) /
                (-4.0 * in.bir * tveg3 + dc1 * wtga + dc2 * wtgaq * qsatldT);
       t_veg = tlbef + dt_veg;
       const double dels = dt_veg;
@@ -1068,13 +1068,13 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       const double tstar = temp1 * dth;
       const double qstar = temp2 * dqh;
       const double thvstar = tstar * (1.0 + 0.61 * in.forc_q) + 0.61 * in.forc_th * qstar;
-      double zeta = zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * in.thv);
+      double zeta = zldis * VKC * GRAV * thvstar / (elmk_sq(ustar) * in.thv);
       if (zeta >= 0.0) {
         zeta = dmin(2.0, dmax(zeta, 0.01));
         um = dmax(in.ur, 0.1);
       } else {
         zeta = dmax(-100.0, dmin(zeta, -0.01));
-        const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / in.thv), 0.333);
+        const double wc = 1.0 * elmk_pow((-GRAV * ustar * thvstar * 1000.0 / in.thv), 0.333);
         um = sqrt(in.ur * in.ur + wc * wc);
       }
       obu = zldis / zeta;
@@ -1211,9 +1211,9 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   const double emv = S->emv[c], emg = S->emg[c], forc_lwrad = S->forc_lwrad[c];
   const double tlbef = f.tlbef, dt_veg = f.dt_veg;
   const double lw_grnd = S->wk[(int64_t)WK_CF_LWGRND * ld + c];
-  S->dlrad[c] = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
+  S->dlrad[c] = (1.0 - emv) * emg * forc_lwrad + emv * emg * STEBOL * elmk_pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg);
   S->ulrad[c] = ((1.0 - emg) * (1.0 - emv) * (1.0 - emv) * forc_lwrad +
-                 emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
+                 emv * (1.0 + (1.0 - emg) * (1.0 - emv)) * STEBOL * elmk_pow(tlbef, 3.0) * (tlbef + 4.0 * dt_veg) +
                  emg * (1.0 - emv) * STEBOL * lw_grnd);
   double cgrnds = 0.0, cgrndl = 0.0;
   cgrnds += CPAIR * forc_rho * wtg * wtal;

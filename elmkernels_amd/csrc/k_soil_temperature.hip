@@ -47,7 +47,7 @@ __device__ __forceinline__ double st_surface_heat_flux(int frac_veg_nosno, doubl
                                                        double htvp, double solar_abg, double temp, double eflx_sh,
                                                        double qflx_ev)
 {
-  return solar_abg + dlrad + (1.0 - frac_veg_nosno) * emg * forc_lwrad - emg * STEBOL * pow(temp, 4.0) -
+  return solar_abg + dlrad + (1.0 - frac_veg_nosno) * emg * forc_lwrad - emg * STEBOL * elmk_pow(temp, 4.0) -
          (eflx_sh + qflx_ev * htvp);
 }
 
@@ -68,12 +68,12 @@ __device__ __forceinline__ void st_level_props(const DevState* __restrict__ S, c
     if (satw > 1.0e-6) {
       double dke;
       if (LV(t_soisno, i) >= TFRZ) {
-        dke = dmax(0.0, log10(satw) + 1.0);
+        dke = dmax(0.0, elmk_log10(satw) + 1.0);
       } else {
         dke = satw;
       }
       const double fl = (liq / (DENH2O * dzl)) / (liq / (DENH2O * dzl) + ice / (DENICE * dzl));
-      const double dksat = LV(tkmg, j) * pow(ST_TKWAT, fl * watsat) * pow(ST_TKICE, (1.0 - fl) * watsat);
+      const double dksat = LV(tkmg, j) * elmk_pow(ST_TKWAT, fl * watsat) * elmk_pow(ST_TKICE, (1.0 - fl) * watsat);
       thk = dke * dksat + (1.0 - dke) * tkdry;
     } else {
       thk = tkdry;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
                                      S->qflx_ev_h2osfc[c]);
     hs_top_snow = st_surface_heat_flux(fvn, dlrad, emg, forc_lwrad, htvp, LV(sabg_lyr, top), LV(t_soisno, top),
                                        S->eflx_sh_snow[c], S->qflx_ev_snow[c]);
-    dhsdT = -S->cgrnd[c] - 4.0 * emg * STEBOL * pow(S->t_grnd[c], 3.0);
+    dhsdT = -S->cgrnd[c] - 4.0 * emg * STEBOL * elmk_pow(S->t_grnd[c], 3.0);
   }
   // heat capacity and height of standing surface water (soil_thermal_properties_impl.hh:255-279)
   double c_h2osfc, dz_h2osfc;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
       if (t < TFRZ) {
         const double smp = HFUS * (TFRZ - t) / (GRAV * t) * 1000.0;
         const int j = i - NLEVSNO;
-        supercool = LV(watsat, j) * pow(smp / LV(sucsat, j), -1.0 / LV(bsw, j));
+        supercool = LV(watsat, j) * elmk_pow(smp / LV(sucsat, j), -1.0 / LV(bsw, j));
         supercool *= LV(dz, i) * 1000.0;
       }
       if (liq > supercool && t < TFRZ) {

@@ -83,11 +83,11 @@ __global__ __launch_bounds__(256) void k_surface_fluxes(const DevState* __restri
   }
   double eflx_soil_grnd = S->eflx_soil_grnd[c];
   if (!urbpoi) {
-    const double lw_grnd = (frac_sno_eff * pow(tssbef_snotop, 4.0) + (1.0 - frac_sno_eff - frac_h2osfc) * pow(tssbef_soitop, 4.0) +
-                            frac_h2osfc * pow(t_h2osfc_bef, 40));
+    const double lw_grnd = (frac_sno_eff * elmk_pow(tssbef_snotop, 4.0) + (1.0 - frac_sno_eff - frac_h2osfc) * elmk_pow(tssbef_soitop, 4.0) +
+                            frac_h2osfc * elmk_pow(t_h2osfc_bef, 40));
     eflx_soil_grnd = ((1.0 - frac_sno_eff) * S->sabg_soil[c] + frac_sno_eff * S->sabg_snow[c]) + S->dlrad[c] +
                      (1.0 - (double)fvn) * emg * forc_lwrad - emg * STEBOL * lw_grnd -
-                     pow(emg * STEBOL * t_grnd0, 3.0) * (4.0 * tinc) - (eflx_sh_grnd + qflx_evap_soi * htvp);
+                     elmk_pow(emg * STEBOL * t_grnd0, 3.0) * (4.0 * tinc) - (eflx_sh_grnd + qflx_evap_soi * htvp);
   }
   const double eflx_sh_veg = S->eflx_sh_veg[c], qflx_evap_veg = S->qflx_evap_veg[c];
   S->eflx_sh_tot[c] = eflx_sh_veg + eflx_sh_grnd;
@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256) void k_surface_fluxes(const DevState* __restri
 
   // ---- lwrad_outgoing (:247-265)
   if (!urbpoi) {
-    const double lw_grnd = (frac_sno_eff * pow(tssbef_snotop, 4.0) + (1.0 - frac_sno_eff - frac_h2osfc) * pow(tssbef_soitop, 4.0) +
-                            frac_h2osfc * pow(t_h2osfc_bef, 4.0));
+    const double lw_grnd = (frac_sno_eff * elmk_pow(tssbef_snotop, 4.0) + (1.0 - frac_sno_eff - frac_h2osfc) * elmk_pow(tssbef_soitop, 4.0) +
+                            frac_h2osfc * elmk_pow(t_h2osfc_bef, 4.0));
     const double out = S->ulrad[c] + (1 - fvn) * (1.0 - emg) * forc_lwrad + (1 - fvn) * emg * STEBOL * lw_grnd +
-                       4.0 * emg * STEBOL * pow(t_grnd0, 3.0) * tinc;
+                       4.0 * emg * STEBOL * elmk_pow(t_grnd0, 3.0) * tinc;
     S->eflx_lwrad_out[c] = out;
     S->eflx_lwrad_net[c] = out - forc_lwrad;
   }

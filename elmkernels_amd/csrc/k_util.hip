@@ -198,4 +198,31 @@ void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st)
   if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// elmk_math.h on the device, element-wise (parity check of the math functions themselves)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_math_eval(int fn, const double* __restrict__ x, const double* __restrict__ y,
+                                                   double* __restrict__ out, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = x[i];
+  double r;
+  switch (fn) {
+    case ELMK_MATH_EXP: r = elmk_exp(a); break;
+    case ELMK_MATH_LOG: r = elmk_log(a); break;
+    case ELMK_MATH_LOG10: r = elmk_log10(a); break;
+    case ELMK_MATH_ATAN: r = elmk_atan(a); break;
+    case ELMK_MATH_SQRT: r = sqrt(a); break;
+    case ELMK_MATH_DIV: r = a / y[i]; break;
+    default: r = elmk_pow(a, y[i]); break;
+  }
+  out[i] = r;
+}
+
+void launch_math_eval(int fn, const double* x, const double* y, double* out, int64_t n, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fn, x, y, out, n);
+}
+
 }  // namespace elmk

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_frac_wet(const DevState* __restrict__ S
     if (h2ocan > 0.0) {
       const double vegt = fvn * (elai + esai);
       const double dewmxi = 1.0 / S->dewmx;
-      fwet = pow(((dewmxi / vegt) * h2ocan), 0.666666666666);
+      fwet = elmk_pow(((dewmxi / vegt) * h2ocan), 0.666666666666);
       fwet = dmin(fwet, 1.0);
     } else {
       fwet = 0.0;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
         fracsnow = forc_snow / (forc_snow + forc_rain);
         fracrain = forc_rain / (forc_snow + forc_rain);
         const double h2ocanmx = S->dewmx * (elai + esai);
-        const double fpi = 0.25 * (1.0 - exp(-0.5 * (elai + esai)));
+        const double fpi = 0.25 * (1.0 - elmk_exp(-0.5 * (elai + esai)));
         qflx_through_snow = forc_snow * (1.0 - fpi);
         qflx_through_rain = forc_rain * (1.0 - fpi);
         const double qflx_prec_intr = (forc_snow + forc_rain) * fpi;
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
   } else {
     double bifall;
     if (forc_t > TFRZ + 2.0) {
-      bifall = 50.0 + 1.7 * pow(17.0, 1.5);
+      bifall = 50.0 + 1.7 * elmk_pow(17.0, 1.5);
     } else if (forc_t > TFRZ - 15.0) {
-      bifall = 50.0 + 1.7 * pow((forc_t - TFRZ + 15.0), 1.5);
+      bifall = 50.0 + 1.7 * elmk_pow((forc_t - TFRZ + 15.0), 1.5);
     } else {
       bifall = 50.0;
     }
@@ -161,13 +161,13 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
     if (h2osno > 0.0) {
       if (snowmelt > 0.0) {
         const double smr = dmin(1.0, (h2osno / int_snow));
-        frac_sno = 1.0 - pow((acos(dmin(1.0, (2.0 * smr - 1.0))) / ELM_PI), n_melt);
+        frac_sno = 1.0 - elmk_pow((acos(dmin(1.0, (2.0 * smr - 1.0))) / ELM_PI), n_melt);
       }
       if (newsnow > 0.0) {
         const double fsno_new = 1.0 - (1.0 - tanh(accum_factor * newsnow)) * (1.0 - frac_sno);
         frac_sno = fsno_new;
         const double temp_intsnow =
-            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
+            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
         int_snow = dmin(1.e8, temp_intsnow);
       }
       if (!L.urbpoi) {  // subgridflag() == 1
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
       }
       if (S->oldfflag == 1) {
         if (snow_depth > 0.0) {
-          frac_sno = tanh(snow_depth / (2.5 * ZLND * pow((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))), 1.0)));
+          frac_sno = tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
         }
         if (h2osno < 1.0) {
           frac_sno = dmin(frac_sno, h2osno);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
         frac_sno = tanh(accum_factor * newsnow);
         int_snow = 0.0;
         const double temp_intsnow =
-            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
+            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
         int_snow = dmin(1.e8, temp_intsnow);
         if (!L.urbpoi) {
           snow_depth = z_avg / frac_sno;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
         if (S->oldfflag == 1) {
           if (snow_depth > 0.0) {
             frac_sno =
-                tanh(snow_depth / (2.5 * ZLND * pow((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))), 1.0)));
+                tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
           }
         }
       } else {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
 #pragma unroll 1
       for (int l = 0; l < 10; l++) {
         const double fd = 0.5 * d * (1.0 + erf(d / (sigma * sqrt(2.0)))) +
-                          sigma / sqrt(2.0 * ELM_PI) * exp(-pow(d, 2) / (2.0 * pow(sigma, 2))) - h2osfc;
+                          sigma / sqrt(2.0 * ELM_PI) * elmk_exp(-elmk_sq(d) / (2.0 * elmk_sq(sigma))) - h2osfc;
         const double dfdd = 0.5 * (1.0 + erf(d / (sigma * sqrt(2.0))));
         d = d - fd / dfdd;
       }
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
         const double wx = (liq_soi0 / DENH2O + ice_soi0 / DENICE) / LV(dz, NLEVSNO);
         double fac = dmin(1.0, wx / LV(watsat, 0));
         fac = dmax(fac, 0.01);
-        double psit = -LV(sucsat, 0) * pow(fac, (-LV(bsw, 0)));
+        double psit = -LV(sucsat, 0) * elmk_pow(fac, (-LV(bsw, 0)));
         psit = dmax(-1.e8, psit);
-        hr = exp(psit / ROVERG / t_soi0);
+        hr = elmk_exp(psit / ROVERG / t_soi0);
         qred = (1.0 - frac_sno - frac_h2osfc) * hr + frac_sno + frac_h2osfc;
       } else if (L.ctype == icol_sunwall || L.ctype == icol_shadewall) {
         qred = 0.0;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
         if (wx < watfc0) {
           double fac_fc = dmin(1.0, wx / watfc0);
           fac_fc = dmax(fac_fc, 0.01);
-          soilbeta = (1.0 - frac_sno - frac_h2osfc) * 0.25 * pow(1.0 - cos(ELM_PI * fac_fc), 2.0) + frac_sno + frac_h2osfc;
+          soilbeta = (1.0 - frac_sno - frac_h2osfc) * 0.25 * elmk_sq(1.0 - cos(ELM_PI * fac_fc)) + frac_sno + frac_h2osfc;
         } else {
           soilbeta = 1.0;
         }
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
       S->emg[c] = emg;
     }
     const double avmuir = 1.0;
-    S->emv[c] = 1.0 - exp(-(elai + esai) / avmuir);
+    S->emv[c] = 1.0 - elmk_exp(-(elai + esai) / avmuir);
     double htvp = HVAP;
     if (liq_top <= 00 && ice_top > 0.0) htvp = HSUB;
     S->htvp[c] = htvp;
@@ -687,15 +687,15 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
     const double tstar = temp1 * dth;
     const double qstar = temp2 * dqh;
     const double thvstar = tstar * (1.0 + 0.61 * forc_q) + 0.61 * forc_th * qstar;
-    z0hg = z0mg / exp(0.13 * pow((ustar * z0mg / 1.5e-5), 0.45));
+    z0hg = z0mg / elmk_exp(0.13 * elmk_pow((ustar * z0mg / 1.5e-5), 0.45));
     z0qg = z0hg;
-    double zeta = zldis * VKC * GRAV * thvstar / (pow(ustar, 2.0) * thv);
+    double zeta = zldis * VKC * GRAV * thvstar / (elmk_sq(ustar) * thv);
     if (zeta >= 0.0) {
       zeta = dmin(2.0, dmax(zeta, 0.01));
       um = dmax(ur, 0.1);
     } else {
       zeta = dmax(-100.0, dmin(zeta, -0.01));
-      const double wc = 1.0 * pow((-GRAV * ustar * thvstar * 1000.0 / thv), 0.333);
+      const double wc = 1.0 * elmk_pow((-GRAV * ustar * thvstar * 1000.0 / thv), 0.333);
       um = sqrt(ur * ur + wc * wc);
     }
     obu = zldis / zeta;

@@ -222,6 +222,21 @@ class ELMState:
         return g.value
 
 
+    def math_eval(self, fn, x, y=None):
+        """elmk_math.h on the device: fn in MATH_FNS; returns fn(x), x / y or pow(x, y)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            assert y.shape == x.shape
+            yp = y.ctypes.data_as(C.c_void_p)
+        self._chk(self.lib.elmk_math_eval(self.ctx, MATH_FNS.index(fn), x.ctypes.data_as(C.c_void_p), yp,
+                                          out.ctypes.data_as(C.c_void_p), x.size), "math_eval")
+        return out
+
+
+MATH_FNS = ["exp", "log", "log10", "atan", "sqrt", "div", "pow"]
 WRAPPER_NAMES = ["frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
                  "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes"]
 KERNEL_NAMES = [

@@ -1,0 +1,80 @@
+/* Host check of elmkernels_amd/csrc/elmk_math.h against the live libm, bit for bit (any two NaNs count as equal).
+ * gcc -O2 -mfma -ffp-contract=off -fopenmp tests/tools/math_host_check.c -lm ; ./a.out <n per class> <seed>
+ * Prints one line per function: "<fn> n=<evaluated> mismatches=<count>" and the first few offending arguments. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../elmkernels_amd/csrc/elmk_math.h"
+
+static inline uint64_t mix(uint64_t z)
+{
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+static inline double u01(uint64_t r) { return (double)(r >> 11) * 0x1p-53; }
+static inline int same(double a, double b)
+{
+  if (a != a && b != b) return 1;
+  return elmk_asu64(a) == elmk_asu64(b);
+}
+static const double YS[] = {3.0, 4.0, 0.333, -0.333, 0.666666666666, 1.5, 2.0, 0.5, -1.0, 40.0, 0.25, 1.0 / 3.0, -0.5, 2.5, 7.0, -2.0};
+
+int main(int argc, char** argv)
+{
+  const long n = argc > 1 ? atol(argv[1]) : 1000000;
+  const uint64_t seed = argc > 2 ? strtoull(argv[2], 0, 0) : 1;
+  long bad[5] = {0, 0, 0, 0, 0}, tot[5] = {0, 0, 0, 0, 0};
+  const char* nm[5] = {"exp", "log", "log10", "pow", "atan"};
+  for (int cls = 0; cls < 6; cls++) {
+    long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+#pragma omp parallel for reduction(+ : b0, b1, b2, b3, b4) schedule(static)
+    for (long j = 0; j < n; j++) {
+      const uint64_t r1 = mix(seed * 1000003ull + (uint64_t)cls * 0x100000000ull + 2 * j), r2 = mix(r1 + 12345), r3 = mix(r2 + 777);
+      double xe, xl, px, py;
+      switch (cls) {
+        case 0: xe = (u01(r1) - 0.5) * 1500.0; xl = exp((u01(r1) - 0.5) * 1400.0); px = xl; py = (u01(r2) - 0.5) * 100.0; break;
+        case 1: xe = (u01(r1) - 0.5) * 2.0; xl = 0.9 + 0.2 * u01(r1); px = 2.0 * u01(r1); py = (u01(r2) - 0.5) * 10.0; break;
+        case 2: xe = elmk_asf64(r1); xl = elmk_asf64(r1 & 0x7fffffffffffffffull); px = elmk_asf64(r1); py = elmk_asf64(r2); break;
+        case 3: xe = (u01(r1) - 0.5) * 100.0; xl = exp((u01(r1) - 0.5) * 46.0); px = 1000.0 * u01(r1); py = YS[r2 & 15]; break;
+        case 4: xe = -745.2 + 40.0 * u01(r1); xl = elmk_asf64(r1 & 0x000fffffffffffffull); /* subnormal */
+                px = -(double)(r1 % 50) * ((r3 & 1) ? 1.0 : 0.37); py = (double)((long)(r2 % 21) - 10) * ((r3 & 2) ? 1.0 : 0.5); break;
+        default: xe = 700.0 + 12.0 * u01(r1); xl = 1.0 + (u01(r1) - 0.5) * 0x1p-20; px = exp((u01(r1) - 0.5) * 2.0); py = (u01(r2) - 0.5) * 3000.0; break;
+      }
+      b0 += !same(exp(xe), elmk_exp(xe));
+      b1 += !same(log(xl), elmk_log(xl));
+      b2 += !same(log10(xl), elmk_log10(xl));
+      b3 += !same(pow(px, py), elmk_pow(px, py));
+      b4 += !same(atan(xe), elmk_atan(xe)) + !same(atan(px), elmk_atan(px));
+    }
+    bad[0] += b0; bad[1] += b1; bad[2] += b2; bad[3] += b3; bad[4] += b4;
+    for (int f = 0; f < 4; f++) tot[f] += n;
+    tot[4] += 2 * n;
+    if (b0 + b1 + b2 + b3 + b4) {  /* show a few */
+      int shown = 0;
+      for (long j = 0; j < n && shown < 4; j++) {
+        const uint64_t r1 = mix(seed * 1000003ull + (uint64_t)cls * 0x100000000ull + 2 * j), r2 = mix(r1 + 12345), r3 = mix(r2 + 777);
+        double xe, xl, px, py;
+        switch (cls) {
+          case 0: xe = (u01(r1) - 0.5) * 1500.0; xl = exp((u01(r1) - 0.5) * 1400.0); px = xl; py = (u01(r2) - 0.5) * 100.0; break;
+          case 1: xe = (u01(r1) - 0.5) * 2.0; xl = 0.9 + 0.2 * u01(r1); px = 2.0 * u01(r1); py = (u01(r2) - 0.5) * 10.0; break;
+          case 2: xe = elmk_asf64(r1); xl = elmk_asf64(r1 & 0x7fffffffffffffffull); px = elmk_asf64(r1); py = elmk_asf64(r2); break;
+          case 3: xe = (u01(r1) - 0.5) * 100.0; xl = exp((u01(r1) - 0.5) * 46.0); px = 1000.0 * u01(r1); py = YS[r2 & 15]; break;
+          case 4: xe = -745.2 + 40.0 * u01(r1); xl = elmk_asf64(r1 & 0x000fffffffffffffull);
+                  px = -(double)(r1 % 50) * ((r3 & 1) ? 1.0 : 0.37); py = (double)((long)(r2 % 21) - 10) * ((r3 & 2) ? 1.0 : 0.5); break;
+          default: xe = 700.0 + 12.0 * u01(r1); xl = 1.0 + (u01(r1) - 0.5) * 0x1p-20; px = exp((u01(r1) - 0.5) * 2.0); py = (u01(r2) - 0.5) * 3000.0; break;
+        }
+        if (!same(exp(xe), elmk_exp(xe))) { printf("  cls %d exp(%a) = %a, got %a\n", cls, xe, exp(xe), elmk_exp(xe)); shown++; }
+        if (!same(log(xl), elmk_log(xl))) { printf("  cls %d log(%a) = %a, got %a\n", cls, xl, log(xl), elmk_log(xl)); shown++; }
+        if (!same(log10(xl), elmk_log10(xl))) { printf("  cls %d log10(%a) = %a, got %a\n", cls, xl, log10(xl), elmk_log10(xl)); shown++; }
+        if (!same(atan(xe), elmk_atan(xe))) { printf("  cls %d atan(%a) = %a, got %a\n", cls, xe, atan(xe), elmk_atan(xe)); shown++; }
+        if (!same(atan(px), elmk_atan(px))) { printf("  cls %d atan(%a) = %a, got %a\n", cls, px, atan(px), elmk_atan(px)); shown++; }
+        if (!same(pow(px, py), elmk_pow(px, py))) { printf("  cls %d pow(%a, %a) = %a, got %a\n", cls, px, py, pow(px, py), elmk_pow(px, py)); shown++; }
+      }
+    }
+  }
+  for (int f = 0; f < 5; f++) printf("%s n=%ld mismatches=%ld\n", nm[f], tot[f], bad[f]);
+  return (bad[0] + bad[1] + bad[2] + bad[3] + bad[4]) != 0;
+}

@@ -32,6 +32,41 @@
 #endif
 #include "elmk_math_tables.h"
 
+// Where the functions read their tables.  Default: the read-only arrays above (device global memory, cached in L1 / L2).
+// A translation unit whose kernels evaluate these functions in their inner loops defines ELMK_MATH_LDS before including
+// this header: the tables are then workgroup-local copies in LDS (a divergent 64-lane gather costs ~100 cycles there
+// instead of a trip through the vector memory pipeline, which a kernel running one or two waves per SIMD cannot hide),
+// and EVERY kernel of that unit that calls one of the functions must execute elmk_math_lds_init<>() first, with all
+// threads of the workgroup, before any early return.
+#if defined(__HIPCC__) && defined(ELMK_MATH_LDS)
+static __shared__ uint64_t elmk_lds_exp_tab[256];
+static __shared__ uint64_t elmk_lds_log_tab[256];
+static __shared__ uint64_t elmk_lds_powlog_tab[384];
+static __shared__ uint64_t elmk_lds_atan_tab[1687];
+#define ELMK_T_EXP elmk_lds_exp_tab
+#define ELMK_T_LOG elmk_lds_log_tab
+#define ELMK_T_POWLOG elmk_lds_powlog_tab
+#define ELMK_T_ATAN elmk_lds_atan_tab
+// exp + log + pow tables (7 KB); WITH_ATAN adds the 13.5 KB atan table
+template <bool WITH_ATAN>
+__device__ __forceinline__ void elmk_math_lds_init()
+{
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    elmk_lds_exp_tab[i] = elmk_exp_tab[i];
+    elmk_lds_log_tab[i] = elmk_log_tab[i];
+  }
+  for (int i = threadIdx.x; i < 384; i += blockDim.x) elmk_lds_powlog_tab[i] = elmk_powlog_tab[i];
+  if (WITH_ATAN)
+    for (int i = threadIdx.x; i < 1687; i += blockDim.x) elmk_lds_atan_tab[i] = elmk_atan_tab[i];
+  __syncthreads();
+}
+#else
+#define ELMK_T_EXP elmk_exp_tab
+#define ELMK_T_LOG elmk_log_tab
+#define ELMK_T_POWLOG elmk_powlog_tab
+#define ELMK_T_ATAN elmk_atan_tab
+#endif
+
 ELMK_MFN uint64_t elmk_asu64(double x)
 {
   union { double f; uint64_t i; } u;
@@ -112,8 +147,8 @@ ELMK_MFN double elmk_exp_core(double x, double xtail, uint32_t sign_bias, int wi
   if (with_tail) r = xtail + r;
   const uint32_t idx = 2u * (uint32_t)(ki & 127u);
   const uint64_t top = (ki + sign_bias) << 45;
-  const double tail = elmk_asf64(elmk_exp_tab[idx]);
-  const uint64_t sbits = elmk_exp_tab[idx + 1] + top;
+  const double tail = elmk_asf64(ELMK_T_EXP[idx]);
+  const uint64_t sbits = ELMK_T_EXP[idx + 1] + top;
   const double tmp = elmk_exp_poly(r, tail);
   if (abstop == 0) return elmk_exp_special(tmp, sbits, ki);
   const double scale = elmk_asf64(sbits);
@@ -183,7 +218,7 @@ ELMK_MFN double elmk_log(double x)
   const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
   const int k = (int)((int64_t)tmp >> 52);
   const uint64_t iz = ix - (tmp & 0xfffull << 52);
-  const double invc = elmk_asf64(elmk_log_tab[2 * i]), logc = elmk_asf64(elmk_log_tab[2 * i + 1]);
+  const double invc = elmk_asf64(ELMK_T_LOG[2 * i]), logc = elmk_asf64(ELMK_T_LOG[2 * i + 1]);
   const double z = elmk_asf64(iz);
   const double kd = (double)k;
   const double r = ELMK_FMA(z, invc, -1.0);
@@ -292,8 +327,8 @@ ELMK_MFN double elmk_pow(double x, double y)
   const uint64_t iz = ix - (tmp & 0xfffull << 52);
   const double z = elmk_asf64(iz);
   const double kd = (double)k;
-  const double invc = elmk_asf64(elmk_powlog_tab[3 * i]), logc = elmk_asf64(elmk_powlog_tab[3 * i + 1]),
-               logctail = elmk_asf64(elmk_powlog_tab[3 * i + 2]);
+  const double invc = elmk_asf64(ELMK_T_POWLOG[3 * i]), logc = elmk_asf64(ELMK_T_POWLOG[3 * i + 1]),
+               logctail = elmk_asf64(ELMK_T_POWLOG[3 * i + 2]);
   const double r = ELMK_FMA(z, invc, -1.0);
   const double t1 = ELMK_FMA(kd, Ln2hi, logc);
   const double t2 = t1 + r;
@@ -350,7 +385,7 @@ ELMK_MFN double elmk_atan(double x)
       return ELMK_FMA(x * v, p, x);
     }
     const int i = (int)(ELMK_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
-    const uint64_t* c = elmk_atan_tab + 7 * i;
+    const uint64_t* c = ELMK_T_ATAN + 7 * i;
     const double z = u - elmk_asf64(c[0]);
     double p = elmk_asf64(c[6]);
     p = ELMK_FMA(z, p, elmk_asf64(c[5]));
@@ -365,7 +400,7 @@ ELMK_MFN double elmk_atan(double x)
     const double a = 1.0 - t1;
     const double t2 = ELMK_FMA(u, w, -t1);
     const int i = (int)(ELMK_FMA(w, 256.0, 0x1p52) - 0x1p52) - 16;
-    const uint64_t* c = elmk_atan_tab + 7 * i;
+    const uint64_t* c = ELMK_T_ATAN + 7 * i;
     const double t3 = a - t2;
     const double zz = w - elmk_asf64(c[0]);
     const double z = ELMK_FMA(t3, w, zz);

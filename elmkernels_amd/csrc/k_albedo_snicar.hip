@@ -21,6 +21,7 @@
 // The ~210 doubles of per-column scratch that the wrapper allocates as zero-filled Views on every call
 // (albedo_kokkos.cc:19-38) shrink to 28 (the SNICAR products).  Lookup tables (Mie [3][5][1471] x2, BC, aerosol) sit
 // in one 355 KB device buffer that stays L2-resident; the gather index is round(snw_rds)-30.
+#define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 
@@ -621,6 +622,7 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict__ S)
 {
+  elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   const Land L = S->land;
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict
 template <int NL>
 __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restrict__ S)
 {
+  elmk_math_lds_init<false>();
   const int64_t ld = S->ld;
   const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
   const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restric
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ S)
 {
+  elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   const Land L = S->land;

@@ -17,6 +17,7 @@
 //     evaluated once per trip (PsnTemp) - 11 exp instead of 22;
 //   * the 30 ViewD1(ncols) temporaries of the wrapper (:11-40) and the 15-level work arrays stay in registers.
 // The arithmetic of each expression (operand order, parenthesisation) is the reference's.
+#define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S
 
 __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 {
+  elmk_math_lds_init<false>();
   __shared__ uint32_t s_w[4][CF_NCLS];
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
@@ -796,6 +798,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
 {
+  elmk_math_lds_init<true>();
   const int64_t ld = S->ld;
   const Land L = S->land;
   const int lane = threadIdx.x & 63;
@@ -1156,6 +1159,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ S, double dtime)
 {
+  elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   if (blockIdx.x == 0 && threadIdx.x < CF_NCLS) CF_CLASS_COUNT(S, threadIdx.x) = 0u;  // for the next call's k_cf_count

@@ -23,6 +23,7 @@
 // layer run over all rows with a predicate, and rows above the snow pack enter the forward sweep as identity rows:
 // with their A, B, Z equal to zero the general recurrence reproduces the reference's special first and second rows
 // exactly (x - 0*y == x), so the solve is bit-identical to the reference's whatever the layer count.
+#define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 
@@ -147,6 +148,7 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
 
 __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
 {
+  elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   if (c >= S->ncols) return;

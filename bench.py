@@ -289,7 +289,7 @@ def main():
                 "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name,
                 "parallelism": f"columns block-split over {world} rank(s) on {min(world, ndev)} GPU(s), no collective",
             }
-            out["roofline"] = {"bound": "hbm", "kernel": "k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_st_props + k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                "bytes_per_column": SOIL_ALGO_BYTES, "avg_launch_ms": ms_total}
         else:

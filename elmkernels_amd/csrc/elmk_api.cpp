@@ -181,7 +181,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t pos_bytes = align_up((size_t)ctx->ld * 4, 256);
   const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
-  const size_t stw_bytes = align_up((size_t)63 * (size_t)ctx->ld * 8, 256);
+  const size_t stw_bytes = align_up((size_t)(40 + 42) * (size_t)ctx->ld * 8, 256);  // soil_temperature: thk, cv of the 20 levels; A, Z of the 21 rows
   const size_t cons_bytes = align_up((size_t)8 * (size_t)ctx->ld * 8 + (size_t)8 * ELMK_CONS_NPART * 3 * 8 + 8 * 3 * 8, 256);
   ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes + stw_bytes + cons_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);

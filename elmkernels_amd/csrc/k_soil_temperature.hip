@@ -98,16 +98,44 @@ __device__ __forceinline__ void st_level_props(const DevState* __restrict__ S, c
   }
 }
 
-// state of the forward sweep of solver::PDMA (pentadiagonal_solver_impl.hh:16-76).  A, B, Z of every row go to the
+// Stage 1 of the wrapper: thermal conductivity and heat capacity of every (level, column), one thread each.  The level is
+// blockIdx.y - the same for the whole workgroup - so branches on it are uniform and every access is a coalesced row.
+// This is where the transcendental work of the wrapper is (two pow and a log10 per soil level); as a launch of its own
+// it runs at full occupancy beside its loads instead of serialised down the column inside the solve.
+// Results: rows ST_ROW_THK + i and ST_ROW_CV + i of the context's st_work scratch.
+constexpr int ST_ROW_THK = 0;
+constexpr int ST_ROW_CV = NLEVTOT;
+__global__ __launch_bounds__(256) void k_st_props(const DevState* __restrict__ S)
+{
+  elmk_math_lds_init<false>();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  if (c >= S->ncols) return;
+  const int i = (int)blockIdx.y;
+  const int snl = S->snl[c];
+  double thk, cv;
+  st_level_props(S, c, ld, i, NLEVSNO - snl, snl, S->frac_sno[c], S->h2osno[c], thk, cv);
+  S->st_work[(int64_t)(ST_ROW_THK + i) * ld + c] = thk;
+  S->st_work[(int64_t)(ST_ROW_CV + i) * ld + c] = cv;
+}
+
+// state of the forward sweep of solver::PDMA (pentadiagonal_solver_impl.hh:16-76).  A and Z of rows 0..18 go to the
 // context's scratch (SoA [row][column] like the state: the row loops are rolled, a register array would need dynamic
-// indexing); the recurrence itself only needs the last two rows, kept here.
+// indexing; an LDS stage [row][thread] was measured: 78 KB per workgroup leaves two waves per SIMD and the solve, which
+// is latency-bound, ran 1.5 x slower).  B = l0 * U1 is zero in every row but one - only the snow layer next to the
+// ground has a second superdiagonal entry (l0, get_matrix_snow_soil) - so that one value stays in a register and the
+// back substitution multiplies by a literal zero elsewhere (the same arithmetic as the reference's 0 * U1 product for
+// every finite solution).  The recurrence itself only needs the last two rows, kept here.
+constexpr int ST_ROW_A = 2 * NLEVTOT;        // rows of st_work after thk, cv
+constexpr int ST_ROW_Z = 2 * NLEVTOT + NROW;
 struct StSweep {
   double* __restrict__ A;  // scratch bases of this column; element of row r at [r * ld]
-  double* __restrict__ B;
   double* __restrict__ Z;
+  double B4;  // B of row NLEVSNO - 1
   double Am2, Am1, Bm2, Bm1, Zm2, Zm1;
   double Y1, U1, r19, l4_19, A19;  // kept from the second row from the bottom for the reference's form of the last two
 };
+constexpr int ST_WG = 256;
 
 // one row of the forward sweep.  Rows above the snow pack arrive as identity rows; with their A, B, Z equal to zero
 // the general recurrence gives the reference's special first and second rows exactly.
@@ -122,8 +150,8 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
     const double b = l0 * U1;
     const double z = (rr - w.Zm2 * l4 - w.Zm1 * Y1) * U1;
     w.A[(int64_t)r * ld] = a;
-    w.B[(int64_t)r * ld] = b;
     w.Z[(int64_t)r * ld] = z;
+    if (r == NLEVSNO - 1) w.B4 = b;
     w.Am2 = w.Am1;
     w.Am1 = a;
     w.Bm2 = w.Bm1;
@@ -146,9 +174,9 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
   }
 }
 
-__global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
+__global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
 {
-  elmk_math_lds_init<false>();
+  elmk_math_lds_init<false>();  // pow in the surface heat fluxes and in the supercooled-water limit of phase change
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   if (c >= S->ncols) return;
@@ -191,28 +219,34 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
   //      superdiagonal, 2 = diagonal, 3 = 1st subdiagonal, 4 = 2nd subdiagonal) and the forward sweep.  Only the
   //      sweep's A, B, Z stay in registers; level quantities live in a sliding window (previous, current, next).
   StSweep w;
-  w.A = S->st_work + c;
-  w.B = S->st_work + (int64_t)NROW * ld + c;
-  w.Z = S->st_work + (int64_t)2 * NROW * ld + c;
+  w.A = S->st_work + (int64_t)ST_ROW_A * ld + c;
+  w.Z = S->st_work + (int64_t)ST_ROW_Z * ld + c;
+  w.B4 = 0.0;
   w.Am2 = w.Am1 = w.Bm2 = w.Bm1 = w.Zm2 = w.Zm1 = 0.0;
   w.Y1 = w.U1 = w.r19 = w.l4_19 = w.A19 = 0.0;
   double fact_sl1 = 0.0;  // matrix factor of the snow layer next to the ground (for phase_change_h2osfc)
-  double thk_cur, cv_cur;
-  st_level_props(S, c, ld, 0, top, snl, frac_sno, h2osno0, thk_cur, cv_cur);
+  const double* __restrict__ props = S->st_work + c;  // stage 1 (k_st_props): rows ST_ROW_THK + i, ST_ROW_CV + i
+  double thk_cur = props[(int64_t)ST_ROW_THK * ld], cv_cur = props[(int64_t)ST_ROW_CV * ld];
   double z_cur = LV(zsoi, 0), t_cur = LV(t_soisno, 0);
   double z_prev = 0.0, tk_prev = 0.0, fn_prev = 0.0;
+  // the level loop is a dependent chain with little work per level: the loads of level i + 2 are issued one trip ahead
+  // of their use (software pipeline), so a wave always has a row of loads in flight
+  double thk_nxt = props[(int64_t)(ST_ROW_THK + 1) * ld], cv_nxt = props[(int64_t)(ST_ROW_CV + 1) * ld];
+  double z_nxt = LV(zsoi, 1), t_nxt = LV(t_soisno, 1), zi_nxt = LV(zisoi, 1);
 #pragma unroll 1
   for (int i = 0; i < NLEVTOT; i++) {
-    double thk_nxt = 0.0, cv_nxt = 0.0, z_nxt = 0.0, t_nxt = 0.0;
-    if (i + 1 < NLEVTOT) {
-      st_level_props(S, c, ld, i + 1, top, snl, frac_sno, h2osno0, thk_nxt, cv_nxt);
-      z_nxt = LV(zsoi, i + 1);
-      t_nxt = LV(t_soisno, i + 1);
+    double thk_n2 = 0.0, cv_n2 = 0.0, z_n2 = 0.0, t_n2 = 0.0, zi_n2 = 0.0;
+    if (i + 2 < NLEVTOT) {
+      thk_n2 = props[(int64_t)(ST_ROW_THK + i + 2) * ld];
+      cv_n2 = props[(int64_t)(ST_ROW_CV + i + 2) * ld];
+      z_n2 = LV(zsoi, i + 2);
+      t_n2 = LV(t_soisno, i + 2);
+      zi_n2 = LV(zisoi, i + 2);
     }
     // calc_face_tk (:132), calc_diffusive_heat_flux (soil_temperature_impl.hh:45): interface i | i+1
     double tk_i = 0.0, fn_i = 0.0;
     if (i < NLEVTOT - 1 && i >= top) {
-      const double zi1 = LV(zisoi, i + 1);
+      const double zi1 = zi_nxt;
       tk_i = thk_cur * thk_nxt * (z_nxt - z_cur) / (thk_cur * (z_nxt - zi1) + thk_nxt * (zi1 - z_cur));
       fn_i = tk_i * (t_nxt - t_cur) / (z_nxt - z_cur);
     }
@@ -301,6 +335,11 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
     fn_prev = fn_i;
     thk_cur = thk_nxt;
     cv_cur = cv_nxt;
+    thk_nxt = thk_n2;
+    cv_nxt = cv_n2;
+    z_nxt = z_n2;
+    t_nxt = t_n2;
+    zi_nxt = zi_n2;
   }
 
   // ---- back substitution (:69-74) and update_temperature (soil_temperature_impl.hh:154-177): row r holds level r for
@@ -316,7 +355,7 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
     t_ssw = 0.0;
 #pragma unroll 1
     for (int r = NROW - 3; r >= 0; --r) {
-      const double x = w.Z[(int64_t)r * ld] - w.A[(int64_t)r * ld] * r1 - w.B[(int64_t)r * ld] * r2;
+      const double x = w.Z[(int64_t)r * ld] - w.A[(int64_t)r * ld] * r1 - ((r == NLEVSNO - 1) ? w.B4 : 0.0) * r2;
       r2 = r1;
       r1 = x;
       if (r > NLEVSNO) {
@@ -616,7 +655,8 @@ __global__ __launch_bounds__(256) void k_soil_temperature(const DevState* __rest
 void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st)
 {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_soil_temperature, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dt);
+  hipLaunchKernelGGL(k_st_props, dim3((unsigned)((n + 255) / 256), NLEVTOT), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_soil_temperature, dim3((unsigned)((n + ST_WG - 1) / ST_WG)), dim3(ST_WG), 0, st, S, dt);
 }
 
 }  // namespace elmk

@@ -447,3 +447,387 @@ ELMK_MFN double elmk_atan(double x)
 // reference's default Debug (-O0) build would return.
 ELMK_MFN double elmk_sq(double x) { return x * x; }
 ELMK_MFN double elmk_pow1(double x) { return x; }
+
+// ---- expm1, tanh: glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c, s_tanh.c (fdlibm; these have no FMA build on x86-64:
+// plain multiplies and adds in the source's order) ------------------------------------------------------------------------
+ELMK_MFN double elmk_with_high_word(double y, uint32_t hi)
+{
+  return elmk_asf64(((uint64_t)hi << 32) | (elmk_asu64(y) & 0xffffffffull));
+}
+ELMK_MFN double elmk_expm1(double x)
+{
+  const double one = 1.0, huge = 1.0e+300, tiny = 1.0e-300, o_threshold = 7.09782712893383973096e+02,
+               ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03, Q3 = -7.93650757867487942473e-05,
+               Q4 = 4.00821782732936239552e-06, Q5 = -2.01099218183624371326e-07;
+  double y, hi, lo, c = 0.0, t, e, hxs, hfx, r1, h2, h4, R1, R2, R3;
+  int32_t k;
+  const uint32_t hx0 = (uint32_t)(elmk_asu64(x) >> 32);
+  const uint32_t xsb = hx0 & 0x80000000u;
+  const uint32_t hx = hx0 & 0x7fffffffu;
+  if (hx >= 0x4043687Au) {    // |x| >= 56 ln2
+    if (hx >= 0x40862E42u) {  // |x| >= 709.78
+      if (hx >= 0x7ff00000u) {
+        if (((hx & 0xfffffu) | (uint32_t)elmk_asu64(x)) != 0) return x + x;  // nan
+        return (xsb == 0) ? x : -1.0;                                       // exp(+-inf) - 1
+      }
+      if (x > o_threshold) return huge * huge;  // overflow
+    }
+    if (xsb != 0) return tiny - one;  // x < -56 ln2: -1 (the reference adds an inexact flag)
+  }
+  if (hx > 0x3fd62e42u) {    // |x| > 0.5 ln2
+    if (hx < 0x3FF0A2B2u) {  // and |x| < 1.5 ln2
+      if (xsb == 0) {
+        hi = x - ln2_hi;
+        lo = ln2_lo;
+        k = 1;
+      } else {
+        hi = x + ln2_hi;
+        lo = -ln2_lo;
+        k = -1;
+      }
+    } else {
+      k = (int32_t)(invln2 * x + ((xsb == 0) ? 0.5 : -0.5));
+      t = (double)k;
+      hi = x - t * ln2_hi;  // t * ln2_hi is exact here
+      lo = t * ln2_lo;
+    }
+    x = hi - lo;
+    c = (hi - x) - lo;
+  } else if (hx < 0x3c900000u) {  // |x| < 2^-54
+    t = huge + x;
+    return x - (t - (huge + x));
+  } else {
+    k = 0;
+  }
+  // x is now in the primary range
+  hfx = 0.5 * x;
+  hxs = x * hfx;
+  R1 = one + hxs * Q1;
+  h2 = hxs * hxs;
+  R2 = Q2 + hxs * Q3;
+  h4 = h2 * h2;
+  R3 = Q4 + hxs * Q5;
+  r1 = R1 + h2 * R2 + h4 * R3;
+  t = 3.0 - r1 * hfx;
+  e = hxs * ((r1 - t) / (6.0 - x * t));
+  if (k == 0) return x - (x * e - hxs);  // c is 0
+  e = (x * (e - c) - c);
+  e -= hxs;
+  if (k == -1) return 0.5 * (x - e) - 0.5;
+  if (k == 1) {
+    if (x < -0.25) return -2.0 * (e - (x + 0.5));
+    return one + 2.0 * (x - e);
+  }
+  if (k <= -2 || k > 56) {  // suffice to return exp(x) - 1
+    y = one - (e - x);
+    y = elmk_with_high_word(y, (uint32_t)(elmk_asu64(y) >> 32) + ((uint32_t)k << 20));
+    return y - one;
+  }
+  if (k < 20) {
+    t = elmk_with_high_word(one, 0x3ff00000u - (0x200000u >> k));  // 1 - 2^-k
+    y = t - (e - x);
+    y = elmk_with_high_word(y, (uint32_t)(elmk_asu64(y) >> 32) + ((uint32_t)k << 20));
+  } else {
+    t = elmk_with_high_word(one, (uint32_t)(0x3ff - k) << 20);  // 2^-k
+    y = x - (e + t);
+    y += one;
+    y = elmk_with_high_word(y, (uint32_t)(elmk_asu64(y) >> 32) + ((uint32_t)k << 20));
+  }
+  return y;
+}
+
+ELMK_MFN double elmk_tanh(double x)
+{
+  const double one = 1.0, two = 2.0, tiny = 1.0e-300;
+  double t, z;
+  const int32_t jx = (int32_t)(elmk_asu64(x) >> 32);
+  const uint32_t lx = (uint32_t)elmk_asu64(x);
+  const int32_t ix = jx & 0x7fffffff;
+  if (ix >= 0x7ff00000) {  // inf or nan
+    if (jx >= 0) return one / x + one;
+    return one / x - one;
+  }
+  if (ix < 0x40360000) {  // |x| < 22
+    if (((uint32_t)ix | lx) == 0) return x;
+    if (ix < 0x3c800000) return x * (one + x);  // |x| < 2^-55
+    if (ix >= 0x3ff00000) {                     // |x| >= 1
+      t = elmk_expm1(two * __builtin_fabs(x));
+      z = one - two / (t + two);
+    } else {
+      t = elmk_expm1(-two * __builtin_fabs(x));
+      z = -t / (t + two);
+    }
+  } else {
+    z = one - tiny;  // |x| >= 22: +-1
+  }
+  return (jx >= 0) ? z : -z;
+}
+
+// ---- cos: glibc 2.35 sysdeps/ieee754/dbl-64/s_sin.c (__cos_fma; IBM Accurate Mathematical Library) --------------------
+// Exact for |x| < 105414350 (0x419921FB in the high word) - the ranges s_sin.c handles with do_cos / do_sin /
+// reduce_sincos.  Beyond that the reference reduces with __branred (Payne-Hanek); no call site of the physics can get
+// there (the arguments are pi * [0, 1]), and this function returns NaN there instead of restating it.
+#define ELMK_SC(k, j) elmk_asf64(elmk_sincos_tab[4 * (k) + (j)])
+ELMK_MFN double elmk_sc_do_cos(double x, double dx)
+{
+  const double big = 0x1.8p+45, sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7, cs2 = 0.5, cs4 = -0x1.5555555555535p-5,
+               cs6 = 0x1.6c16bedd9e239p-10;
+  if (x < 0) dx = -dx;
+  const double ax = __builtin_fabs(x);
+  const double u = big + ax;
+  x = (ax - (u - big)) + dx;
+  const int k = (int)(uint32_t)elmk_asu64(u);
+  const double xx = x * x;
+  const double ps = ELMK_FMA(xx, sn5, sn3);
+  const double s = ELMK_FMA(x * xx, ps, x);
+  double pc = ELMK_FMA(xx, cs6, cs4);
+  pc = ELMK_FMA(xx, pc, cs2);
+  const double c = xx * pc;
+  const double sn = ELMK_SC(k, 0), ssn = ELMK_SC(k, 1), cs = ELMK_SC(k, 2), ccs = ELMK_SC(k, 3);
+  double cor = ELMK_FMA(-s, ssn, ccs);
+  cor = ELMK_FMA(-c, cs, cor);
+  cor = ELMK_FMA(-s, sn, cor);
+  return cs + cor;
+}
+ELMK_MFN double elmk_sc_do_sin(double x, double dx)
+{
+  const double big = 0x1.8p+45, sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7, cs2 = 0.5, cs4 = -0x1.5555555555535p-5,
+               cs6 = 0x1.6c16bedd9e239p-10;
+  const double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7, s3 = -0x1.a01a019db08b8p-13, s4 = 0x1.71de27b9a7ed9p-19,
+               s5 = -0x1.addffc2fcdf59p-26;
+  const double xold = x;
+  if (__builtin_fabs(x) < 0.126) {  // TAYLOR_SIN(x * x, x, dx)
+    const double xx = x * x;
+    double p = ELMK_FMA(xx, s5, s4);
+    p = ELMK_FMA(xx, p, s3);
+    p = ELMK_FMA(xx, p, s2);
+    p = ELMK_FMA(xx, p, s1);
+    const double q = ELMK_FMA(p, x, -(0.5 * dx));
+    const double t = ELMK_FMA(xx, q, dx);
+    return x + t;
+  }
+  if (x <= 0) dx = -dx;
+  const double ax = __builtin_fabs(x);
+  const double u = big + ax;
+  x = ax - (u - big);
+  const int k = (int)(uint32_t)elmk_asu64(u);
+  const double xx = x * x;
+  const double ps = ELMK_FMA(xx, sn5, sn3);
+  const double sd = ELMK_FMA(x * xx, ps, dx);
+  double pc = ELMK_FMA(xx, cs6, cs4);
+  pc = ELMK_FMA(xx, pc, cs2);
+  const double s = x + sd;
+  const double c = ELMK_FMA(x, dx, xx * pc);
+  const double sn = ELMK_SC(k, 0), ssn = ELMK_SC(k, 1), cs = ELMK_SC(k, 2), ccs = ELMK_SC(k, 3);
+  double cor = ELMK_FMA(s, ccs, ssn);
+  cor = ELMK_FMA(-c, sn, cor);
+  cor = ELMK_FMA(s, cs, cor);
+  return elmk_atan_signed(sn + cor, xold);  // copysign
+}
+ELMK_MFN double elmk_cos(double x)
+{
+  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54, hpinv = 0x1.45f306dc9c883p-1, toint = 0x1.8p+52,
+               mp1 = 0x1.921fb58p+0, mp2 = -0x1.dde973cp-27, pp3 = -0x1.cb3b398p-55, pp4 = -0x1.d747f23e32ed7p-83;
+  const uint32_t k = (uint32_t)(elmk_asu64(x) >> 32) & 0x7fffffffu;
+  if (k < 0x3e400000u) return 1.0;                      // |x| < 2^-27
+  if (k < 0x3feb6000u) return elmk_sc_do_cos(x, 0.0);  // |x| < 0.855469
+  if (k < 0x400368fdu) {                                // |x| < 2.426265
+    const double y = hp0 - __builtin_fabs(x);
+    const double a = y + hp1;
+    const double da = (y - a) + hp1;
+    return elmk_sc_do_sin(a, da);
+  }
+  if (k < 0x419921FBu) {  // |x| < 105414350: reduce_sincos, then do_sincos(a, da, n + 1)
+    const double t = ELMK_FMA(x, hpinv, toint);
+    const double xn = t - toint;
+    const int n = ((int)(uint32_t)elmk_asu64(t) & 3) + 1;
+    double y = ELMK_FMA(-xn, mp1, x);
+    y = ELMK_FMA(-xn, mp2, y);
+    const double t2 = ELMK_FMA(-xn, pp3, y);
+    double db = ELMK_FMA(-pp3, xn, y - t2);
+    const double b = ELMK_FMA(-xn, pp4, t2);
+    db = db + ELMK_FMA(-xn, pp4, t2 - b);
+    const double r = (n & 1) ? elmk_sc_do_cos(b, db) : elmk_sc_do_sin(b, db);
+    return (n & 2) ? -r : r;
+  }
+  if (k < 0x7ff00000u) return ELMK_NAN;  // outside the restated range (see above)
+  return x / x;                          // inf, nan
+}
+
+// ---- erf: glibc 2.35 sysdeps/ieee754/dbl-64/s_erf.c (fdlibm rational approximations in glibc's pairwise-grouped form;
+// no FMA build; the two exp() calls of the 1.25 <= |x| < 6 range are the new exp above) -----------------------------------
+ELMK_MFN double elmk_erf(double x)
+{
+  const double one = 1.0, tiny = 1e-300, erx = 0x1.b0ac16p-1, efx = 0x1.06eba8214db69p-3, efx16 = 0x1.06eba8214db69p+1;
+  const int32_t hx = (int32_t)(elmk_asu64(x) >> 32);
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix >= 0x7ff00000) {  // erf(nan) = nan, erf(+-inf) = +-1
+    const int i = (int)(((uint32_t)hx >> 31) << 1);
+    return (double)(1 - i) + one / x;
+  }
+  if (ix < 0x3feb0000) {    // |x| < 0.84375
+    if (ix < 0x3e300000) {  // |x| < 2^-28
+      if (ix < 0x00800000) return 0.0625 * (16.0 * x + efx16 * x);  // avoid underflow
+      return x + efx * x;
+    }
+    const double z = x * x;
+    const double r1 = 0x1.06eba8214db68p-3 + z * -0x1.4cd7d691cb913p-2;
+    const double z2 = z * z;
+    const double r2 = z * -0x1.7a291236668e4p-8 - 0x1.d2a51dbd7194fp-6;
+    const double z4 = z2 * z2;
+    const double s1 = one + z * 0x1.97779cddadc09p-2;
+    const double s2 = 0x1.0a54c5536cebap-4 + z * 0x1.4d022c4d36b0fp-8;
+    const double s3 = 0x1.15dc9221c1a1p-13 + z * -0x1.09c4342a2612p-18;
+    const double r = r1 + z2 * r2 + z4 * -0x1.8ead6120016acp-16;
+    const double s = s1 + z2 * s2 + z4 * s3;
+    const double y = r / s;
+    return x + x * y;
+  }
+  if (ix < 0x3ff40000) {  // 0.84375 <= |x| < 1.25
+    const double s = __builtin_fabs(x) - one;
+    const double P1 = s * 0x1.a8d00ad92b34dp-2 - 0x1.359b8bef77538p-9;
+    const double s2 = s * s;
+    const double Q1 = one + s * 0x1.b3e6618eee323p-4;
+    const double s4 = s2 * s2;
+    const double P2 = s * 0x1.45fca805120e4p-2 - 0x1.7d240fbb8c3f1p-2;
+    const double s6 = s4 * s2;
+    const double Q2 = 0x1.14af092eb6f33p-1 + s * 0x1.2635cd99fe9a7p-4;
+    const double P3 = s * 0x1.22a36599795ebp-5 - 0x1.c63983d3e28ecp-4;
+    const double Q3 = 0x1.02660e763351fp-3 + s * 0x1.bedc26b51dd1cp-7;
+    const double P4 = -0x1.1bf380a96073fp-9;
+    const double Q4 = 0x1.88b545735151dp-7;
+    const double P = P1 + s2 * P2 + s4 * P3 + s6 * P4;
+    const double Q = Q1 + s2 * Q2 + s4 * Q3 + s6 * Q4;
+    if (hx >= 0) return erx + P / Q;
+    return -erx - P / Q;
+  }
+  if (ix >= 0x40180000) {  // 6 <= |x| < inf
+    if (hx >= 0) return one - tiny;
+    return tiny - one;
+  }
+  const double ax = __builtin_fabs(x);
+  const double s = one / (ax * ax);
+  double R, S;
+  if (ix < 0x4006DB6E) {  // |x| < 1 / 0.35
+    const double R1 = s * -0x1.63416e4ba736p-1 - 0x1.43412600d6435p-7;
+    const double s2 = s * s;
+    const double S1 = one + s * 0x1.3a6b9bd707687p+4;
+    const double s4 = s2 * s2;
+    const double R2 = s * -0x1.f300ae4cba38dp+5 - 0x1.51e0441b0e726p+3;
+    const double s6 = s4 * s2;
+    const double S2 = 0x1.1350c526ae721p+7 + s * 0x1.b290dd58a1a71p+8;
+    const double s8 = s4 * s4;
+    const double R3 = s * -0x1.7135cebccabb2p+7 - 0x1.44cb184282266p+7;
+    const double S3 = 0x1.42b1921ec2868p+9 + s * 0x1.ad02157700314p+8;
+    const double R4 = s * -0x1.3a0efc69ac25cp+3 - 0x1.4526557e4d2f2p+6;
+    const double S4 = 0x1.b28a3ee48ae2cp+6 + s * 0x1.a47ef8e484a93p+2;
+    R = R1 + s2 * R2 + s4 * R3 + s6 * R4;
+    S = S1 + s2 * S2 + s4 * S3 + s6 * S4 + s8 * -0x1.eeff2ee749a62p-5;
+  } else {  // |x| >= 1 / 0.35
+    const double R1 = s * -0x1.993ba70c285dep-1 - 0x1.4341239e86f4ap-7;
+    const double s2 = s * s;
+    const double S1 = one + s * 0x1.e568b261d519p+4;
+    const double s4 = s2 * s2;
+    const double R2 = s * -0x1.4145d43c5ed98p+7 - 0x1.1c209555f995ap+4;
+    const double s6 = s4 * s2;
+    const double S2 = 0x1.45cae221b9f0ap+8 + s * 0x1.802eb189d5118p+10;
+    const double R3 = s * -0x1.004616a2e5992p+10 - 0x1.3ec881375f228p+9;
+    const double S3 = 0x1.8ffb7688c246ap+11 + s * 0x1.3f219cedf3be6p+11;
+    const double S4 = 0x1.da874e79fe763p+8 + s * -0x1.670e242712d62p+4;
+    R = R1 + s2 * R2 + s4 * R3 + s6 * -0x1.e384e9bdc383fp+8;
+    S = S1 + s2 * S2 + s4 * S3 + s6 * S4;
+  }
+  const double z = elmk_asf64(elmk_asu64(ax) & 0xffffffff00000000ull);
+  const double r = elmk_exp(-z * z - 0.5625) * elmk_exp((z - ax) * (z + ax) + R / S);
+  if (hx >= 0) return one - r / ax;
+  return r / ax - one;
+}
+
+// ---- acos: glibc 2.35 sysdeps/ieee754/dbl-64/e_asin.c (__ieee754_acos, FMA build; IBM Accurate Mathematical Library, the
+// version without the multi-precision fall-backs) -----------------------------------------------------------------------
+#define ELMK_AS(i) elmk_asf64(elmk_asncs_tab[i])
+// the table ranges share one shape: xx = |x| - x_i (with x's sign folded in), a polynomial of degree deg in xx whose last
+// coefficient is at n + deg + 1, then asin(x_i) in two pieces
+ELMK_MFN double elmk_acos_row(double x, int positive, int n, int deg)
+{
+  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+  const double xx = (positive ? x : -x) - ELMK_AS(n);
+  double p = ELMK_AS(n + deg);
+  for (int j = deg - 1; j >= 2; --j) p = ELMK_FMA(xx, p, ELMK_AS(n + j));
+  p = ELMK_FMA(xx * xx, p, ELMK_AS(n + deg + 1));
+  const double t = ELMK_FMA(xx, ELMK_AS(n + 1), p);
+  const double y = ELMK_AS(n + deg + 2);
+  if (positive) return (hp1 - t) + (hp0 - y);
+  return (t + hp1) + (y + hp0);
+}
+ELMK_MFN double elmk_acos(double x)
+{
+  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+  const double f1 = 0x1.55555555554f9p-3, f2 = 0x1.333333336127dp-4, f3 = 0x1.6db6dae42c0e4p-5, f4 = 0x1.f1c7e04f4ad99p-6,
+               f5 = 0x1.6e442c822d419p-6, f6 = 0x1.292d80f453c72p-6;
+  const int32_t m = (int32_t)(elmk_asu64(x) >> 32);
+  const uint32_t lo = (uint32_t)elmk_asu64(x);
+  const int32_t k = m & 0x7fffffff;
+  if (k < 0x3c880000) return hp0;  // |x| < 2^-55
+  if (k < 0x3fc00000) {            // |x| < 0.125
+    const double x2 = x * x;
+    double p = ELMK_FMA(x2, f6, f5);
+    p = ELMK_FMA(x2, p, f4);
+    p = ELMK_FMA(x2, p, f3);
+    p = ELMK_FMA(x2, p, f2);
+    p = ELMK_FMA(x2, p, f1);
+    const double r = hp0 - x;
+    double cor = hp0 - r;
+    const double x3 = x * x2;
+    cor = cor - x;
+    cor = cor + hp1;
+    cor = ELMK_FMA(-p, x3, cor);
+    return r + cor;
+  }
+  if (k < 0x3fe00000) {  // |x| < 0.5
+    const int n = (k < 0x3fd00000) ? 11 * ((k & 0x000f8000) >> 15) : 11 * ((k & 0x000fc000) >> 14) + 352;
+    return elmk_acos_row(x, m > 0, n, 6);
+  }
+  if (k < 0x3fe80000) return elmk_acos_row(x, m > 0, 1056 + 12 * ((k >> 13) & 0x7f), 7);  // |x| < 0.75
+  if (k < 0x3fed8000) return elmk_acos_row(x, m > 0, 992 + 13 * ((k >> 13) & 0x7f), 8);   // |x| < 0.921875
+  if (k < 0x3fee8000) return elmk_acos_row(x, m > 0, 884 + 14 * ((k >> 13) & 0x7f), 9);   // |x| < 0.953125
+  if (k < 0x3fef0000) return elmk_acos_row(x, m > 0, 768 + 15 * ((k >> 13) & 0x7f), 10);  // |x| < 0.96875
+  if (k < 0x3ff00000) {  // |x| < 1: acos(|x|) = 2 asin(sqrt((1 - |x|) / 2)), the root by table seed + one Newton step
+    const double rt0 = 0x1.fffffffecc1ddp-1, rt1 = 0x1.fffffff757304p-2, rt2 = 0x1.800496769c91ap-2, rt3 = 0x1.4006318d1dab9p-2;
+    const double z = 0.5 * ((m > 0) ? (1.0 - x) : (1.0 + x));
+    const uint32_t hz = (uint32_t)(elmk_asu64(z) >> 32);
+    double t = elmk_asf64(elmk_inroot_tab[(hz >> 14) & 0x7f]) * elmk_asf64((uint64_t)(0x3ff + 511 - (int)(hz >> 21)) << 52);
+    const double r = ELMK_FMA(-(t * t), z, 1.0);
+    double q = ELMK_FMA(r, rt3, rt2);
+    q = ELMK_FMA(r, q, rt1);
+    q = ELMK_FMA(r, q, rt0);
+    t = q * t;
+    const double c = z * t;
+    const double h = ELMK_FMA(-c, 0.5 * t, 1.5);
+    const double w = ELMK_FMA(c, 0x1p27, c);
+    const double y = ELMK_FMA(-0x1p27, c, w);
+    const double ty = ELMK_FMA(h, c, y);
+    const double cc = ELMK_FMA(-y, y, z) / ty;
+    double p = ELMK_FMA(z, f6, f5);
+    p = ELMK_FMA(z, p, f4);
+    p = ELMK_FMA(z, p, f3);
+    p = ELMK_FMA(z, p, f2);
+    p = ELMK_FMA(z, p, f1);
+    p = p * z;
+    const double pc = p * (y + cc);
+    if (m >= 0) {
+      double res = cc + pc;
+      res = res + y;
+      return res + res;
+    }
+    const double a = hp1 - cc;
+    const double b = hp0 - y;
+    double res = a - pc;
+    res = res + b;
+    return res + res;
+  }
+  if (k == 0x3ff00000 && lo == 0) return (m > 0) ? 0.0 : 0x1.921fb54442d18p+1;  // acos(1) = 0, acos(-1) = pi
+  if (k > 0x7ff00000 || (k == 0x7ff00000 && lo != 0)) return x + x;               // nan
+  return ELMK_NAN;                                                                // |x| > 1
+}

@@ -214,6 +214,11 @@ __global__ __launch_bounds__(256) void k_math_eval(int fn, const double* __restr
     case ELMK_MATH_LOG10: r = elmk_log10(a); break;
     case ELMK_MATH_ATAN: r = elmk_atan(a); break;
     case ELMK_MATH_SQRT: r = sqrt(a); break;
+    case ELMK_MATH_TANH: r = elmk_tanh(a); break;
+    case ELMK_MATH_COS: r = elmk_cos(a); break;
+    case ELMK_MATH_ERF: r = elmk_erf(a); break;
+    case ELMK_MATH_ACOS: r = elmk_acos(a); break;
+    case ELMK_MATH_EXPM1: r = elmk_expm1(a); break;
     case ELMK_MATH_DIV: r = a / y[i]; break;
     default: r = elmk_pow(a, y[i]); break;
   }

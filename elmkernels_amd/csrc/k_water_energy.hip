@@ -161,13 +161,13 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
     if (h2osno > 0.0) {
       if (snowmelt > 0.0) {
         const double smr = dmin(1.0, (h2osno / int_snow));
-        frac_sno = 1.0 - elmk_pow((acos(dmin(1.0, (2.0 * smr - 1.0))) / ELM_PI), n_melt);
+        frac_sno = 1.0 - elmk_pow((elmk_acos(dmin(1.0, (2.0 * smr - 1.0))) / ELM_PI), n_melt);
       }
       if (newsnow > 0.0) {
-        const double fsno_new = 1.0 - (1.0 - tanh(accum_factor * newsnow)) * (1.0 - frac_sno);
+        const double fsno_new = 1.0 - (1.0 - elmk_tanh(accum_factor * newsnow)) * (1.0 - frac_sno);
         frac_sno = fsno_new;
         const double temp_intsnow =
-            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
+            (h2osno + newsnow) / (0.5 * (elmk_cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
         int_snow = dmin(1.e8, temp_intsnow);
       }
       if (!L.urbpoi) {  // subgridflag() == 1
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
       }
       if (S->oldfflag == 1) {
         if (snow_depth > 0.0) {
-          frac_sno = tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
+          frac_sno = elmk_tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
         }
         if (h2osno < 1.0) {
           frac_sno = dmin(frac_sno, h2osno);
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
     } else {
       if (newsnow > 0.0) {
         const double z_avg = newsnow / bifall;
-        frac_sno = tanh(accum_factor * newsnow);
+        frac_sno = elmk_tanh(accum_factor * newsnow);
         int_snow = 0.0;
         const double temp_intsnow =
-            (h2osno + newsnow) / (0.5 * (cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
+            (h2osno + newsnow) / (0.5 * (elmk_cos(ELM_PI * elmk_pow((1.0 - dmax(frac_sno, 1.e-6)), (1.0 / n_melt))) + 1.0));
         int_snow = dmin(1.e8, temp_intsnow);
         if (!L.urbpoi) {
           snow_depth = z_avg / frac_sno;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
         if (S->oldfflag == 1) {
           if (snow_depth > 0.0) {
             frac_sno =
-                tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
+                elmk_tanh(snow_depth / (2.5 * ZLND * elmk_pow1((dmin(800.0, ((h2osno + newsnow) / snow_depth / 100.0))))));
           }
         }
       } else {
@@ -256,12 +256,12 @@ __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __rest
       const double sigma = 1.0e3 * S->micro_sigma[c];
 #pragma unroll 1
       for (int l = 0; l < 10; l++) {
-        const double fd = 0.5 * d * (1.0 + erf(d / (sigma * sqrt(2.0)))) +
+        const double fd = 0.5 * d * (1.0 + elmk_erf(d / (sigma * sqrt(2.0)))) +
                           sigma / sqrt(2.0 * ELM_PI) * elmk_exp(-elmk_sq(d) / (2.0 * elmk_sq(sigma))) - h2osfc;
-        const double dfdd = 0.5 * (1.0 + erf(d / (sigma * sqrt(2.0))));
+        const double dfdd = 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
         d = d - fd / dfdd;
       }
-      frac_h2osfc = 0.5 * (1.0 + erf(d / (sigma * sqrt(2.0))));
+      frac_h2osfc = 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
     } else {
       frac_h2osfc = 0.0;
       LV(h2osoi_liq, NLEVSNO) = LV(h2osoi_liq, NLEVSNO) + h2osfc;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
         if (wx < watfc0) {
           double fac_fc = dmin(1.0, wx / watfc0);
           fac_fc = dmax(fac_fc, 0.01);
-          soilbeta = (1.0 - frac_sno - frac_h2osfc) * 0.25 * elmk_sq(1.0 - cos(ELM_PI * fac_fc)) + frac_sno + frac_h2osfc;
+          soilbeta = (1.0 - frac_sno - frac_h2osfc) * 0.25 * elmk_sq(1.0 - elmk_cos(ELM_PI * fac_fc)) + frac_sno + frac_h2osfc;
         } else {
           soilbeta = 1.0;
         }

@@ -236,7 +236,7 @@ class ELMState:
         return out
 
 
-MATH_FNS = ["exp", "log", "log10", "atan", "sqrt", "div", "pow"]
+MATH_FNS = ["exp", "log", "log10", "atan", "sqrt", "tanh", "cos", "erf", "acos", "expm1", "div", "pow"]
 WRAPPER_NAMES = ["frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
                  "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes"]
 KERNEL_NAMES = [

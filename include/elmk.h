@@ -231,10 +231,13 @@ int elmk_read_scratch(elmk_ctx *ctx, int kind, void *host, int64_t offset, int64
  * empirical HBM line next to the 8 TB/s datasheet peak */
 int elmk_copy_bandwidth(elmk_ctx *ctx, int64_t bytes, int iters, double *gbytes_per_s);
 /* Evaluate one function of elmkernels_amd/csrc/elmk_math.h - the device restatement of the host libm's exp / log / log10 /
- * pow / atan (the <cmath> calls of src/physics headers) - on n host values: out[i] = fn(x[i]) or pow(x[i], y[i]).
+ * pow / atan / tanh / cos / erf / acos / expm1 (the <cmath> calls of src/physics headers) - on n host values: out[i] = fn(x[i]) or pow(x[i], y[i]).
  * ELMK_MATH_SQRT and ELMK_MATH_DIV (x[i] / y[i]) are the device's own IEEE operations, included so that the tests can
  * confirm they round correctly.  y is read only for ELMK_MATH_POW / ELMK_MATH_DIV.  Used by the parity tests to compare the device bits with the host libm's. */
-typedef enum { ELMK_MATH_EXP = 0, ELMK_MATH_LOG, ELMK_MATH_LOG10, ELMK_MATH_ATAN, ELMK_MATH_SQRT, ELMK_MATH_DIV, ELMK_MATH_POW } elmk_math_fn;
+typedef enum {
+  ELMK_MATH_EXP = 0, ELMK_MATH_LOG, ELMK_MATH_LOG10, ELMK_MATH_ATAN, ELMK_MATH_SQRT, ELMK_MATH_TANH, ELMK_MATH_COS, ELMK_MATH_ERF,
+  ELMK_MATH_ACOS, ELMK_MATH_EXPM1, ELMK_MATH_DIV, ELMK_MATH_POW
+} elmk_math_fn;
 int elmk_math_eval(elmk_ctx *ctx, int fn, const double *x, const double *y, double *out, int64_t n);
 
 #ifdef __cplusplus

@@ -58,14 +58,11 @@ CANCEL_SCALE = {
     "qflx_tran_veg": 1e-3, "qflx_evap_veg": 1e-3, "qflx_evap_soi": 1e-3, "qflx_ev_snow": 1e-3, "qflx_ev_soil": 1e-3,
     "qflx_ev_h2osfc": 1e-3, "qflx_evap_tot": 1e-3, "h2ocan": 2.0,
 }
-# Bit-exactness.  exp / log / log10 / pow / atan on the device are restatements of the host libm's algorithms
-# (elmkernels_amd/csrc/elmk_math.h; sqrt and division are correctly rounded on both sides), so on bit-identical inputs every
-# fp64 output must be BIT-IDENTICAL to the oracle's - except the few that pass through tanh / acos / cos / erf, which are
-# still the device libm's (canopy_hydrology's snow-cover fraction, new-snow-layer geometry and ponded fraction;
-# canopy_temperature's soilbeta).  Those are held to REL_TOL.
-LIBM_RESIDUAL_FIELDS = {
-    "frac_sno", "frac_sno_eff", "snow_depth", "int_snow", "frac_h2osfc", "dz", "zsoi", "zisoi", "soilbeta",
-}
+# Bit-exactness.  Every <cmath> function the hot path calls - exp, log, log10, pow, atan, tanh, cos, erf, acos - is on the
+# device a restatement of the host libm's algorithm (elmkernels_amd/csrc/elmk_math.h; sqrt and division are correctly
+# rounded on both sides), so on bit-identical inputs every fp64 output must be BIT-IDENTICAL to the oracle's.  The set
+# below lists outputs exempt from that (held to REL_TOL instead): none.
+LIBM_RESIDUAL_FIELDS = set()
 
 
 # soil_temperature phase change (used by its test only): what is left of a layer's ice, of a thin snow cover or of a

@@ -1,4 +1,4 @@
-"""elmkernels_amd/csrc/elmk_math.h (the device's exp / log / log10 / pow / atan) compiled for the host with gcc and compared
+"""elmkernels_amd/csrc/elmk_math.h (the device's exp / log / log10 / pow / atan / expm1 / tanh / cos / erf / acos) compiled for the host with gcc and compared
 with the live libm - the one the oracle and the reference call - bit for bit.  The header's purpose and provenance are in
 its own comment; tools/gen_libm_tables.py writes the table file it includes."""
 import os
@@ -24,12 +24,12 @@ def checker(tmp_path_factory):
 
 @pytest.mark.parametrize("seed", [1, 20261004])
 def test_host_build_of_device_math_matches_libm_bit_for_bit(checker, seed):
-    """6 argument classes x 3 M arguments per function (physics ranges, whole exponent range, random bit patterns,
+    """6 argument classes x 2 M arguments (x 1-3 variants) per function (physics ranges, whole exponent range, random bit patterns,
     subnormals, over/underflow edges, the exponents the physics uses): zero mismatches."""
-    r = subprocess.run([checker, "3000000", str(seed)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([checker, "2000000", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if "mismatches=" in ln]
-    assert len(lines) == 5 and all(ln.endswith("mismatches=0") for ln in lines), r.stdout
+    assert len(lines) == 10 and all(ln.endswith("mismatches=0") for ln in lines), r.stdout
 
 
 def test_table_header_is_what_the_live_libm_holds(tmp_path):

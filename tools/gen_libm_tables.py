@@ -81,6 +81,27 @@ for i in range(241):
     assert abs(atan_tab[7 * i] - (i + 16) / 256) < 1 / 300 and abs(atan_tab[7 * i + 1] - math.atan(atan_tab[7 * i])) < 1e-13, i
     assert abs(atan_tab[7 * i + 2] - 1 / (1 + atan_tab[7 * i] ** 2)) < 1e-12, i  # c2 = atan'(x_i)
 
+# ---- sin / cos (IBM Accurate Mathematical Library, sysdeps/ieee754/dbl-64/s_sin.c + sincostab.c): __sincostab[440],
+# entry k = {sin(x_k) high, low, cos(x_k) high, low} for x_k = k / 128; located by its first non-trivial entry
+sc_offs = find_all(d(0.0) + d(0.0) + d(1.0) + d(0.0) + d(float.fromhex("0x1.fffeaaaaeeeefp-8")))
+sincos_tab = doubles(sc_offs[0], 440)
+assert all(doubles(o, 440) == sincos_tab for o in sc_offs)
+for k in range(110):
+    assert abs(sincos_tab[4 * k] + sincos_tab[4 * k + 1] - math.sin(k / 128)) < 1e-15 and abs(sincos_tab[4 * k + 2] - math.cos(k / 128)) < 1e-15, k
+
+# ---- asin / acos (IBM Accurate Mathematical Library, sysdeps/ieee754/dbl-64/e_asin.c + asincos.tbl, root.tbl): asncs[2568]
+# (rows {x_i, c1.., asin(x_i) high, low} of five different lengths for the ranges of |x| in [0.125, 0.96875)) and
+# inroot[128] (1/sqrt seeds); located by their first entries
+as_offs = find_all(d(float.fromhex("0x1.04p-3")) + d(float.fromhex("0x1.0216988994424p+0")))
+asncs_tab = doubles(as_offs[0], 2568)
+assert all(doubles(o, 2568) == asncs_tab for o in as_offs)
+assert abs(asncs_tab[8] - math.asin(asncs_tab[0])) < 1e-15 and abs(asncs_tab[1] - 1 / math.sqrt(1 - asncs_tab[0] ** 2)) < 1e-15
+ir_offs = find_all(d(float.fromhex("0x1.68a1f80d7182p+0")) + d(float.fromhex("0x1.65de82af9631fp+0")))
+inroot_tab = doubles(ir_offs[0], 128)
+assert all(doubles(o, 128) == inroot_tab for o in ir_offs)
+for i in range(128):  # 1/sqrt of the midpoint of the i-th of 128 intervals of [0.5, 2)
+    assert 0.70 < inroot_tab[i] < 1.42, i
+
 ver = subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
 
 
@@ -114,4 +135,10 @@ with open(OUT, "w") as f:
     f.write(emit("elmk_powlog_tab", [pow_tab[4 * i + j] for i in range(N) for j in (0, 2, 3)], per=3))
     f.write("// s_atan.c cij[241][7]: {x_i, atan(x_i), c2..c6}, x_i ~ (i + 16) / 256\n")
     f.write(emit("elmk_atan_tab", atan_tab, per=7))
+    f.write("// sincostab.c __sincostab[440]: {sin hi, sin lo, cos hi, cos lo} of k / 128\n")
+    f.write(emit("elmk_sincos_tab", sincos_tab, per=4))
+    f.write("// asincos.tbl asncs[2568]\n")
+    f.write(emit("elmk_asncs_tab", asncs_tab, per=4))
+    f.write("// root.tbl inroot[128]\n")
+    f.write(emit("elmk_inroot_tab", inroot_tab, per=4))
 print("wrote", os.path.normpath(OUT), "exp@%#x log@%#x pow_log@%#x" % (exp_off, log_off, pow_off))

@@ -90,11 +90,13 @@ class ELMState:
             raise ValueError(f"{name}: size {a.size} is not a multiple of nlev {nlev}")
         self._chk(self.lib.elmk_upload(self.ctx, fid, a.ctypes.data, col0, n, layout), f"upload({name})")
 
-    def download(self, name, col0=0, n=None, layout=LAYOUT_COL_MAJOR):
+    def download(self, name, col0=0, n=None, layout=LAYOUT_COL_MAJOR, out=None):
         fid, nlev, dt = self.fields[name]
         n = self.ncols - col0 if n is None else n
         shape = (n,) if nlev == 1 else ((n, nlev) if layout == LAYOUT_COL_MAJOR else (nlev, n))
-        out = np.empty(shape, dtype=dt)
+        if out is None:
+            out = np.empty(shape, dtype=dt)
+        assert out.shape == shape and out.dtype == dt and out.flags.c_contiguous
         self._chk(self.lib.elmk_download(self.ctx, fid, out.ctypes.data, col0, n, layout), f"download({name})")
         return out
 

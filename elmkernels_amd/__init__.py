@@ -16,6 +16,9 @@ from .state import (  # noqa: F401
     kokkos_soil_temperature,
     kokkos_surface_fluxes,
     kokkos_init_timestep,
+    get_forcing,
+    compute_phenology,
+    forcing_time_weights,
     kokkos_evaluate_conservation,
     kokkos_canopy_hydrology,
     kokkos_canopy_temperature,

@@ -582,6 +582,23 @@ int elmk_init_timestep(elmk_ctx* ctx)
   return ELMK_OK;
 }
 
+int elmk_get_forcing(elmk_ctx* ctx, const double* wt1, const double* wt2, int qbot_is_rh)
+{
+  PHYSICS_PROLOGUE();
+  if (!wt1 || !wt2) return invalid(ctx, "elmk_get_forcing: null weights");
+  launch_get_forcing(ctx->d, ctx->ncols, wt1, wt2, qbot_is_rh != 0, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_phenology(elmk_ctx* ctx, double wt1, double wt2)
+{
+  PHYSICS_PROLOGUE();
+  launch_phenology(ctx->d, ctx->ncols, wt1, wt2, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
 int elmk_surface_fluxes(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();

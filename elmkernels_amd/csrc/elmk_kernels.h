@@ -33,6 +33,9 @@ void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_
 constexpr int ELMK_CONS_NPART = 512;  // stage-1 partials per diagnostic
 void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_init_timestep(const DevState* S, int64_t n, hipStream_t st);
+// the forcing and phenology functors kokkos_init_timestep runs first (k_forcing.hip)
+void launch_get_forcing(const DevState* S, int64_t n, const double* wt1, const double* wt2, int qbot_is_rh, hipStream_t st);
+void launch_phenology(const DevState* S, int64_t n, double wt1, double wt2, hipStream_t st);
 void launch_conservation(const DevState* S, int64_t n, int64_t ld, double dt, const double* diag, double* part, double* out,
                          hipStream_t st);
 

@@ -281,6 +281,27 @@ def kokkos_soil_temperature(S, dt):
     S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")
 
 
+def get_forcing(S, wt1, wt2, qbot_is_rh=False):
+    """ELM::get_forcing (atm_forcing_kokkos.cc:47-75); wt1, wt2: [8] weights of TBOT, PBOT, QBOT|RH, FLDS, FSDS, PREC, WIND, ZBOT."""
+    w1 = np.ascontiguousarray(wt1, dtype=np.float64)
+    w2 = np.ascontiguousarray(wt2, dtype=np.float64)
+    assert w1.shape == (8,) and w2.shape == (8,)
+    S._chk(S.lib.elmk_get_forcing(S.ctx, w1.ctypes.data_as(C.c_void_p), w2.ctypes.data_as(C.c_void_p), int(bool(qbot_is_rh))), "get_forcing")
+
+
+def compute_phenology(S, wt1, wt2):
+    """ComputePhenology (phenology_physics_impl.hh:22-69) as update_phenology runs it (phenology_kokkos.cc:59-62)."""
+    S._chk(S.lib.elmk_phenology(S.ctx, float(wt1), float(wt2)), "phenology")
+
+
+def forcing_time_weights(days_since_record, forc_dt):
+    """AtmDataManager::forcing_time_weights (atm_data_impl.hh:191-199): (wt1, wt2) for a model time `days_since_record`
+    days after the forcing record t_idx, records `forc_dt` days apart."""
+    e = days_since_record / forc_dt
+    assert 0.0 <= e <= 1.0
+    return 1.0 - e, e
+
+
 def kokkos_init_timestep(S):
     """The per-column kernel of kokkos_init_timestep (init_timestep_kokkos.cc:55-75)."""
     S._chk(S.lib.elmk_init_timestep(S.ctx), "init_timestep")

@@ -236,4 +236,50 @@ def make_state(field_table, n, tier="A", seed=0x5EEDE1A0, perturb=True):
         cols["h2osno_old"] = cols["h2osno"].copy()
     if "frac_veg_nosno_alb" in cols:
         cols["frac_veg_nosno_alb"] = cols["frac_veg_nosno"].copy()
+    if "atm_tbot" in cols:
+        cols.update(forcing_streams(cols, seed))
     return cols, scal, soil
+
+
+def forcing_streams(cols, seed):
+    """Raw forcing records (t_idx, t_idx + 1) and monthly phenology (start_idx, + 1) around the column's current forcing, for
+    the init_timestep functors: values on both sides of every clamp of atm_physics_impl.hh (tbot > 323, pbot < 4e4,
+    qbot < 1e-9, flds outside / inside (50, 600), negative precipitation and shortwave) and of phenology_physics_impl.hh
+    (lai below 0.05, snow burial of short and tall vegetation)."""
+    n = cols["forc_tbot"].shape[0]
+    rng = np.random.default_rng(seed + 977)
+
+    def two(base, rel=0.05, add=0.0):
+        a = np.empty((n, 2))
+        a[:, 0] = base * (1 + rel * (rng.random(n) - 0.5)) + add * (rng.random(n) - 0.5)
+        a[:, 1] = base * (1 + rel * (rng.random(n) - 0.5)) + add * (rng.random(n) - 0.5)
+        return a
+
+    out = {}
+    tb = two(cols["forc_tbot"], 0.0, 8.0)
+    tb[rng.random(n) < 0.02] = 330.0
+    out["atm_tbot"] = tb
+    pb = two(cols["forc_pbot"])
+    pb[rng.random(n) < 0.02] = 3.0e4
+    out["atm_pbot"] = pb
+    qb = two(cols["forc_qbot"], 0.2)
+    qb[rng.random(n) < 0.02] = 0.0
+    out["atm_qbot"] = qb
+    fl = two(cols["forc_lwrad"], 0.1)
+    sel = rng.random(n)
+    fl[sel < 0.15] = 20.0
+    fl[sel > 0.9] = 700.0
+    out["atm_flds"] = fl
+    out["atm_fsds"] = two(np.where(cols["coszen"] > 0, 600.0, 0.0), 0.8, 0.0) - 30.0 * (rng.random((n, 2)) < 0.05)
+    pr = two((cols["forc_rain"] + cols["forc_snow"]) + 1e-5, 0.5)
+    pr[rng.random(n) < 0.05] = -1e-6
+    out["atm_prec"] = pr
+    out["atm_wind"] = two(np.hypot(cols["forc_u"], cols["forc_v"]), 0.3)
+    lai = 3.0 * rng.random(n)
+    lai[rng.random(n) < 0.1] = 0.03
+    out["mlai"] = two(lai, 0.3)
+    out["msai"] = two(0.3 * lai + 0.02, 0.3)
+    top = np.where(rng.random(n) < 0.5, 0.5, 17.0) * (0.5 + rng.random(n))
+    out["mhtop"] = two(top, 0.05)
+    out["mhbot"] = two(0.1 * top, 0.05)
+    return out

@@ -26,6 +26,9 @@
  *   kokkos_bareground_fluxes(S)     bareground_fluxes_kokkos.hh       elmk_bareground_fluxes
  *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
  *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7
+ *   get_forcing(S, dt, date)        atm_forcing_kokkos.cc:47-75       elmk_get_forcing
+ *   update_phenology: ComputePhenology  phenology_kokkos.cc:59-62     elmk_phenology
+ *   kokkos_init_timestep's kernel   init_timestep_kokkos.cc:55-75     elmk_init_timestep
  *   kokkos_soil_temperature(S,dt)   soil_temperature_kokkos.hh        elmk_soil_temperature
  *   kokkos_surface_fluxes(S,dt)     surface_fluxes_kokkos.hh          elmk_surface_fluxes
  *   kokkos_evaluate_conservation    conserved_quantity_kokkos.hh      elmk_evaluate_conservation
@@ -195,6 +198,20 @@ int elmk_surface_fluxes(elmk_ctx *ctx, double dt);
  * dtbegin_column_h2o (what the conservation check starts from), snow capping flag, frac_veg_nosno, frac_iceold.
  * (The forcing / phenology readers before it in that wrapper are I/O and stay with the caller.) */
 int elmk_init_timestep(elmk_ctx *ctx);
+/* get_forcing (driver/kokkos/atm_forcing_kokkos.cc:47-75), called by kokkos_init_timestep (init_timestep_kokkos.cc:47):
+ * the eight ComputeAtmForcing_* functors of src/physics/atm_physics_impl.hh:27-203 - TBOT, PBOT, QBOT|RH, FLDS, FSDS,
+ * PREC, WIND, ZBOT - over the fields atm_tbot .. atm_wind (level 0 = forcing record t_idx, level 1 = t_idx + 1 of
+ * AtmDataManager::data; upload `data + t_idx * ncells` with ELMK_LAYOUT_SOA) and coszen.  Writes forc_tbot, forc_thbot,
+ * forc_pbot, forc_qbot, forc_lwrad, forc_solad, forc_solai, forc_rain, forc_snow, forc_u, forc_v, forc_hgt,
+ * forc_hgt_{u,t,q}_patch.  wt1, wt2: [8] host doubles in that stream order = AtmDataManager::forcing_time_weights
+ * (src/data/atm_data_impl.hh:191-199) of each stream (ignored for FSDS, PREC, ZBOT); qbot_is_rh != 0: the humidity
+ * stream holds relative humidity in per cent (AtmForcType::RH).  Picking t_idx and the weights is date arithmetic on
+ * the host (forc_t_idx_check_bounds, atm_data_impl.hh:147-169) and stays with the caller, as do the file readers. */
+int elmk_get_forcing(elmk_ctx *ctx, const double *wt1, const double *wt2, int qbot_is_rh);
+/* ComputePhenology (src/physics/phenology_physics_impl.hh:22-69), run by update_phenology (phenology_kokkos.cc:59-62,
+ * called at init_timestep_kokkos.cc:43) over the fields mlai, msai, mhtop, mhbot (level 0 = month start_idx, level 1 =
+ * start_idx + 1 of PhenologyDataManager).  Writes tlai, tsai, htop, hbot, elai, esai, frac_veg_nosno_alb. */
+int elmk_phenology(elmk_ctx *ctx, double wt1, double wt2);
 /* kokkos_evaluate_conservation(S, dt) (conserved_quantity_kokkos.cc:8-81).  The reference keeps its eight
  * diagnostics in wrapper-local Views and prints column 0; here min_max_sum[8][3] receives (min, max, sum) over the
  * context's columns of dtend_column_h2o, errh2o, errh2osno, dwb, errsol, errlon, errseb, netrad - what a multi-GPU

@@ -149,7 +149,11 @@ typedef struct {
   X(eflx_soil_grnd, D, 1) X(eflx_lwrad_out, D, 1) X(eflx_lwrad_net, D, 1) X(qflx_evap_grnd, D, 1)            \
   X(qflx_sub_snow, D, 1) X(qflx_dew_snow, D, 1) X(qflx_dew_grnd, D, 1) X(soil_e_balance, D, 1)               \
   X(dtbegin_column_h2o, D, 1) X(h2osno_old, D, 1) X(qflx_sl_top_soil, D, 1)                                  \
-  X(frac_veg_nosno_alb, I, 1)
+  X(frac_veg_nosno_alb, I, 1)                                                                               \
+  /* kokkos_init_timestep forcing + phenology functors: forcing records t_idx, t_idx + 1; months start_idx, + 1 */ \
+  X(forc_hgt, D, 1) X(hbot, D, 1) X(atm_tbot, D, 2) X(atm_pbot, D, 2) X(atm_qbot, D, 2) X(atm_flds, D, 2)     \
+  X(atm_fsds, D, 2) X(atm_prec, D, 2) X(atm_wind, D, 2) X(mlai, D, 2) X(msai, D, 2) X(mhtop, D, 2)            \
+  X(mhbot, D, 2)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -220,6 +224,14 @@ void elmo_surface_fluxes(elmo_state *S, double dt);
 /* the per-column kernel of kokkos_init_timestep (init_timestep_kokkos.cc:55-75): h2osno_old, dtbegin_column_h2o,
    ELM::init_timestep (init_timestep_impl.hh:7-42) */
 void elmo_init_timestep(elmo_state *S);
+/* get_forcing (driver/kokkos/atm_forcing_kokkos.cc:47-75): the eight ComputeAtmForcing_* functors of
+   src/physics/atm_physics_impl.hh:27-203 in the wrapper's order (TBOT, PBOT, QBOT|RH, FLDS, FSDS, PREC, WIND, ZBOT).
+   wt1, wt2 [8]: AtmDataManager::forcing_time_weights of each stream (atm_data_impl.hh:191-199; unused for FSDS, PREC,
+   ZBOT); qbot_is_rh: the humidity stream holds relative humidity (AtmForcType::RH) */
+void elmo_get_forcing(elmo_state *S, const double *wt1, const double *wt2, int qbot_is_rh);
+/* ComputePhenology (src/physics/phenology_physics_impl.hh:22-69), as run by update_phenology
+   (driver/kokkos/phenology_kokkos.cc:59-62) */
+void elmo_phenology(elmo_state *S, double wt1, double wt2);
 void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag);
 /* probes matching ref_harness.cc (the parts of this path the reference's headers build for) */
 void elmo_soil_thermal(elmo_state *S, double *thk_out, double *tk_out, double *cv_out, double *scal_out);

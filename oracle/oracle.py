@@ -76,6 +76,8 @@ class _Lib:
         L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
         L.elmo_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
         L.elmo_init_timestep.argtypes = [C.c_void_p]
+        L.elmo_get_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.elmo_phenology.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.elmo_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.elmo_pdma.argtypes = [C.c_int64] + [C.c_void_p] * 3
         L.elmo_phase_change.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
@@ -98,6 +100,9 @@ class _Lib:
             if hasattr(R, "elmref_init_timestep"):
                 R.elmref_init_timestep.argtypes = [C.c_void_p]
                 R.elmref_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+            if hasattr(R, "elmref_get_forcing"):
+                R.elmref_get_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                R.elmref_phenology.argtypes = [C.c_void_p, C.c_double, C.c_double]
 
 
 _LIB = None
@@ -259,6 +264,16 @@ class OracleState:
 
     def init_timestep(self, lib=None):
         (self._L.lib.elmo_init_timestep if lib is None else lib.elmref_init_timestep)(self.ptr)
+
+    def get_forcing(self, wt1, wt2, qbot_is_rh=False, lib=None):
+        """get_forcing (atm_forcing_kokkos.cc:47-75); wt1, wt2: [8] weights of TBOT, PBOT, QBOT|RH, FLDS, FSDS, PREC, WIND, ZBOT."""
+        w1 = np.ascontiguousarray(wt1, dtype=np.float64)
+        w2 = np.ascontiguousarray(wt2, dtype=np.float64)
+        assert w1.shape == (8,) and w2.shape == (8,)
+        (self._L.lib.elmo_get_forcing if lib is None else lib.elmref_get_forcing)(self.ptr, w1.ctypes.data, w2.ctypes.data, int(bool(qbot_is_rh)))
+
+    def phenology(self, wt1, wt2, lib=None):
+        (self._L.lib.elmo_phenology if lib is None else lib.elmref_phenology)(self.ptr, float(wt1), float(wt2))
 
     def surface_fluxes(self, dt, lib=None):
         (self._L.lib.elmo_surface_fluxes if lib is None else lib.elmref_surface_fluxes)(self.ptr, float(dt))

@@ -34,6 +34,8 @@
 #include "conserved_quantity_evaluators.h"
 #include "surface_fluxes.h"
 #include "init_timestep.h"
+#include "atm_physics.h"
+#include "phenology_physics.h"
 
 #include "elm_oracle.h"
 
@@ -433,5 +435,66 @@ void elmref_init_timestep(elmo_state* S)
     ELM::init_timestep(S->land.lakpoi != 0, S->veg_active[c] != 0, S->frac_veg_nosno_alb[c], S->snl[c], S->h2osno[c],
                        V(h2osoi_ice, 20), V(h2osoi_liq, 20), S->do_capsnow[c], S->frac_veg_nosno[c], V(frac_iceold, 20));
   }
+}
+// get_forcing (atm_forcing_kokkos.cc:47-75): the reference's own functors over the two bracketing records of each stream
+// ([record][cell], as AtmDataManager::data), each applied to every cell in the wrapper's order
+void elmref_get_forcing(elmo_state* S, const double* wt1, const double* wt2, int qbot_is_rh)
+{
+  using namespace ELM::atm_forcing_physics;
+  const int n = (int)S->ncols;
+  auto stream = [n](const double* f) {  // [col][2] of the oracle state -> [2][col]
+    AD2 a(2, n);
+    for (int c = 0; c < n; c++) {
+      a(0, c) = f[c * 2];
+      a(1, c) = f[c * 2 + 1];
+    }
+    return a;
+  };
+  AD2 tb = stream(S->atm_tbot), pb = stream(S->atm_pbot), qb = stream(S->atm_qbot), fl = stream(S->atm_flds),
+      fs = stream(S->atm_fsds), pr = stream(S->atm_prec), wd = stream(S->atm_wind);
+  AD1 forc_tbot(n, S->forc_tbot), forc_thbot(n, S->forc_thbot), forc_pbot(n, S->forc_pbot), forc_qbot(n, S->forc_qbot),
+      forc_lwrad(n, S->forc_lwrad), coszen(n, S->coszen), forc_rain(n, S->forc_rain), forc_snow(n, S->forc_snow),
+      forc_u(n, S->forc_u), forc_v(n, S->forc_v), forc_hgt(n, S->forc_hgt), hu(n, S->forc_hgt_u_patch),
+      ht(n, S->forc_hgt_t_patch), hq(n, S->forc_hgt_q_patch);
+  AD2 solai(n, 2, S->forc_solai), solad(n, 2, S->forc_solad);
+  const int t_idx = 0;
+  ProcessTBOT<AD1, AD2> f0(t_idx, wt1[0], wt2[0], tb, forc_tbot, forc_thbot);
+  ProcessPBOT<AD1, AD2> f1(t_idx, wt1[1], wt2[1], pb, forc_pbot);
+  ProcessQBOT<AD1, AD2, ELM::AtmForcType::QBOT> f2q(t_idx, wt1[2], wt2[2], qb, forc_tbot, forc_pbot, forc_qbot);
+  ProcessQBOT<AD1, AD2, ELM::AtmForcType::RH> f2r(t_idx, wt1[2], wt2[2], qb, forc_tbot, forc_pbot, forc_qbot);
+  ProcessFLDS<AD1, AD2> f3(t_idx, wt1[3], wt2[3], fl, forc_pbot, forc_qbot, forc_tbot, forc_lwrad);
+  ProcessFSDS<AD1, AD2> f4(t_idx, fs, coszen, solai, solad);
+  ProcessPREC<AD1, AD2> f5(t_idx, pr, forc_tbot, forc_rain, forc_snow);
+  ProcessWIND<AD1, AD2> f6(t_idx, wt1[6], wt2[6], wd, forc_u, forc_v);
+  ProcessZBOT<AD1> f7(forc_hgt, hu, ht, hq);
+  for (int c = 0; c < n; c++) f0(c);
+  for (int c = 0; c < n; c++) f1(c);
+  for (int c = 0; c < n; c++) qbot_is_rh ? f2r(c) : f2q(c);
+  for (int c = 0; c < n; c++) f3(c);
+  for (int c = 0; c < n; c++) f4(c);
+  for (int c = 0; c < n; c++) f5(c);
+  for (int c = 0; c < n; c++) f6(c);
+  for (int c = 0; c < n; c++) f7(c);
+}
+
+// ComputePhenology (phenology_physics_impl.hh:22-69) over the two bracketing months ([month][cell])
+void elmref_phenology(elmo_state* S, double wt1, double wt2)
+{
+  const int n = (int)S->ncols;
+  auto months = [n](const double* f) {
+    AD2 a(2, n);
+    for (int c = 0; c < n; c++) {
+      a(0, c) = f[c * 2];
+      a(1, c) = f[c * 2 + 1];
+    }
+    return a;
+  };
+  AD2 mlai = months(S->mlai), msai = months(S->msai), mhtop = months(S->mhtop), mhbot = months(S->mhbot);
+  AD1 snow_depth(n, S->snow_depth), frac_sno(n, S->frac_sno), elai(n, S->elai), esai(n, S->esai), htop(n, S->htop),
+      hbot(n, S->hbot), tlai(n, S->tlai), tsai(n, S->tsai);
+  AI1 vtype(n, S->vtype), fvna(n, S->frac_veg_nosno_alb);
+  ELM::phenology::ComputePhenology<AI1, AD1, AD2> f(mlai, msai, mhtop, mhbot, snow_depth, frac_sno, vtype, wt1, wt2, 0, elai,
+                                                    esai, htop, hbot, tlai, tsai, fvna);
+  for (int c = 0; c < n; c++) f(c);
 }
 } // extern "C"

@@ -358,6 +358,44 @@ def test_init_timestep_column_kernel():
     D.close()
 
 
+def test_get_forcing_and_phenology():
+    """The per-column functors kokkos_init_timestep runs first - get_forcing's eight ComputeAtmForcing_* functors (specific-
+    and relative-humidity streams) and ComputePhenology - on records / months on both sides of every clamp: every field
+    bit-identical to the oracle, which is pinned bit for bit against the reference's own headers (test_oracle_vs_ref)."""
+    rng = np.random.default_rng(5)
+    for rh in (False, True):
+        D, S = _pair(20000, "B", 71)
+        if rh:
+            q = np.clip(S["atm_qbot"] * 4000.0, 0.0, 100.0)
+            S["atm_qbot"][...] = q
+            D["atm_qbot"] = q
+        e = rng.random(8)
+        st.get_forcing(D, 1.0 - e, e, rh)
+        S.get_forcing(1.0 - e, e, rh)
+        _check(D, S, f"get_forcing rh={rh}", bitwise=True)
+        assert (S["forc_tbot"] == 323.0).any() and (S["forc_pbot"] == 4.0e4).any() and (S["forc_lwrad"] != S["atm_flds"][:, 0]).any()
+        D.close()
+    D, S = _pair(20000, "B", 72)
+    vt = S["vtype"].copy()
+    vt[::7] = 0
+    vt[1::7] = 14
+    S["vtype"][...] = vt
+    D["vtype"] = vt
+    st.compute_phenology(D, 0.3, 0.7)
+    S.phenology(0.3, 0.7)
+    _check(D, S, "phenology", bitwise=True)
+    # and into the step: phenology -> forcing -> init_timestep kernel -> the seven wrappers, still bit-identical
+    e = rng.random(8)
+    st.get_forcing(D, 1.0 - e, e)
+    S.get_forcing(1.0 - e, e)
+    st.kokkos_init_timestep(D)
+    S.init_timestep()
+    st.timestep7(D, DT)
+    S.timestep7(DT)
+    _check(D, S, "init_timestep functors -> timestep7", bitwise=True)
+    D.close()
+
+
 def _libm():
     import ctypes
     import ctypes.util

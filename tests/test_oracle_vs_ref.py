@@ -266,3 +266,33 @@ def test_init_timestep_column_kernel_bitwise(states):
     B.init_timestep(lib=O.Reference().R)
     assert not _same(A, B)
     assert np.array_equal(A["h2osno_old"], A["h2osno"]) and (A["do_capsnow"] == (A["h2osno"] > 1000.0)).all()
+
+
+def test_get_forcing_and_phenology_bitwise(states):
+    """kokkos_init_timestep's per-column functors ahead of its own kernel: the eight ComputeAtmForcing_* functors
+    (atm_physics_impl.hh) in get_forcing's order, specific- and relative-humidity streams, and ComputePhenology, against
+    the reference's own headers: every state field bit for bit.  The synthetic records sit on both sides of every clamp."""
+    R = O.Reference().R
+    if not hasattr(R, "elmref_get_forcing"):
+        pytest.skip("oracle/_ref predates the forcing harness")
+    rng = np.random.default_rng(5)
+    for rh in (False, True):
+        A, B = states[0].clone(), states[0].clone()
+        if rh:
+            for X in (A, B):
+                X["atm_qbot"][...] = np.clip(X["atm_qbot"] * 4000.0, 0.0, 100.0)  # per cent
+        e = rng.random(8)
+        A.get_forcing(1.0 - e, e, rh)
+        B.get_forcing(1.0 - e, e, rh, lib=R)
+        assert not _same(A, B)
+        assert (A["forc_tbot"] == 323.0).any() and (A["forc_pbot"] == 4.0e4).any() and (A["forc_hgt_u_patch"] == 30.0).all()
+        assert (A["forc_lwrad"] == 700.0).sum() == 0 and np.isfinite(A["forc_lwrad"]).all() and (A["forc_solad"] >= 0).all()
+        assert (A["forc_rain"] >= 0).all() and (A["forc_snow"] >= 0).all() and ((A["forc_rain"] > 0) & (A["forc_snow"] > 0)).any()
+    A, B = states[0].clone(), states[0].clone()
+    for X in (A, B):
+        X["vtype"][::7] = 0   # bare
+        X["vtype"][1::7] = 14  # taller than the shrub limit: the 0.2 m burial rule
+    A.phenology(0.3, 0.7)
+    B.phenology(0.3, 0.7, lib=R)
+    assert not _same(A, B)
+    assert (A["frac_veg_nosno_alb"] == 0).any() and (A["frac_veg_nosno_alb"] == 1).any() and (A["elai"] == 0).any()

@@ -345,7 +345,7 @@ __device__ __forceinline__ void snicar_combine(const int g0, const int pass, con
 }
 
 __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                           const double coszen, const double elai, const double esai,
+                                           const bool day, const double coszen, const double elai, const double esai,
                                            const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
                                            const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha);
 
@@ -414,38 +414,51 @@ __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, c
 }
 
 // ground_albedo (:155-167), flux_absorption_factor (:171-211, subgridflag == 1) and two_stream_solver (:323-687,
-// nlevcan == 1) for one sunlit column, given soil albedos and the SNICAR products; stores every output.
+// nlevcan == 1) for one sunlit column, given soil albedos and the SNICAR products; for a column without sun (day ==
+// false) the values surface_albedo::init_timestep leaves (:90-151) and snow_albedo_radiation_factor's "no sun" branch
+// (snow_snicar_impl.hh:758-765).  Every output is STORED BY ALL LANES TOGETHER: a wave that holds sunlit and dark
+// columns would otherwise write every 128-byte line twice, half of it each time (measured: 904 instead of 490 bytes
+// per column written by this kernel on the fixture-tiled state).
 __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                           const double coszen, const double elai, const double esai,
+                                           const bool day, const double coszen, const double elai, const double esai,
                                            const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
                                            const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha)
 {
   // ---- ground_albedo (:155-167) and flux_absorption_factor (:171-211, subgridflag == 1)
-  double albgrd[2], albgri[2];
+  double albgrd[2] = {0.0, 0.0}, albgri[2] = {0.0, 0.0};
 #pragma unroll
   for (int ib = 0; ib < 2; ib++) {
-    albgrd[ib] = albsod[ib] * (1.0 - frac_sno) + sd.alb[ib] * frac_sno;
-    albgri[ib] = albsoi[ib] * (1.0 - frac_sno) + si.alb[ib] * frac_sno;
-    LV(albsod, ib) = albsod[ib];
-    LV(albsoi, ib) = albsoi[ib];
-    LV(albsnd, ib) = sd.alb[ib];
-    LV(albsni, ib) = si.alb[ib];
+    double o_sod = 0.0, o_soi = 0.0, o_snd = 0.0, o_sni = 0.0;
+    if (day) {
+      albgrd[ib] = albsod[ib] * (1.0 - frac_sno) + sd.alb[ib] * frac_sno;
+      albgri[ib] = albsoi[ib] * (1.0 - frac_sno) + si.alb[ib] * frac_sno;
+      o_sod = albsod[ib];
+      o_soi = albsoi[ib];
+      o_snd = sd.alb[ib];
+      o_sni = si.alb[ib];
+    }
+    LV(albsod, ib) = o_sod;
+    LV(albsoi, ib) = o_soi;
+    LV(albsnd, ib) = o_snd;
+    LV(albsni, ib) = o_sni;
     LV(albgrd, ib) = albgrd[ib];
     LV(albgri, ib) = albgri[ib];
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    double dv, dn, iv, in;
-    if (L.ltype == istdlak) {
-      dv = sd.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[0]) * (sd.fabs_[i][0] / (1.0 - sd.alb[0])));
-      iv = si.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[0]) * (si.fabs_[i][0] / (1.0 - si.alb[0])));
-      dn = sd.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[1]) * (sd.fabs_[i][1] / (1.0 - sd.alb[1])));
-      in = si.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[1]) * (si.fabs_[i][1] / (1.0 - si.alb[1])));
-    } else {
-      dv = sd.fabs_[i][0] * (1.0 - sd.alb[0]);
-      iv = si.fabs_[i][0] * (1.0 - si.alb[0]);
-      dn = sd.fabs_[i][1] * (1.0 - sd.alb[1]);
-      in = si.fabs_[i][1] * (1.0 - si.alb[1]);
+    double dv = 0.0, dn = 0.0, iv = 0.0, in = 0.0;
+    if (day) {
+      if (L.ltype == istdlak) {
+        dv = sd.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[0]) * (sd.fabs_[i][0] / (1.0 - sd.alb[0])));
+        iv = si.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[0]) * (si.fabs_[i][0] / (1.0 - si.alb[0])));
+        dn = sd.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[1]) * (sd.fabs_[i][1] / (1.0 - sd.alb[1])));
+        in = si.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[1]) * (si.fabs_[i][1] / (1.0 - si.alb[1])));
+      } else {
+        dv = sd.fabs_[i][0] * (1.0 - sd.alb[0]);
+        iv = si.fabs_[i][0] * (1.0 - si.alb[0]);
+        dn = sd.fabs_[i][1] * (1.0 - sd.alb[1]);
+        in = si.fabs_[i][1] * (1.0 - si.alb[1]);
+      }
     }
     LV(flx_absdv, i) = dv;
     LV(flx_absdn, i) = dn;
@@ -457,7 +470,20 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
   double albd[2], albi[2], ftdd[2], ftid[2], ftii[2], fabd[2], fabi[2], fabi_sun[2], fabi_sha[2];
   double fsun_z = 0.0, fabd_sun_z = 0.0, fabd_sha_z = 0.0, fabi_sun_z = 0.0, fabi_sha_z = 0.0;
   const bool soilcrop = (L.ltype == istsoil || L.ltype == istcrop);
-  if (soilcrop && (elai + esai) > 0.0) {  // vegsol
+  if (!day) {  // init_timestep's values (:117-135)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      fabd[ib] = 0.0;
+      fabi[ib] = 0.0;
+      fabi_sun[ib] = 0.0;
+      fabi_sha[ib] = 0.0;
+      ftdd[ib] = 0.0;
+      ftid[ib] = 0.0;
+      ftii[ib] = 0.0;
+      albd[ib] = 1.0;
+      albi[ib] = 1.0;
+    }
+  } else if (soilcrop && (elai + esai) > 0.0) {  // vegsol
     const double* __restrict__ A = S->pft_alb[S->vtype[c]];  // rhol[2] rhos[2] taul[2] taus[2] xl
     const double t_veg = S->t_veg[c], fwet = S->fwet[c];
     const double omegas[2] = {0.8, 0.4};
@@ -702,74 +728,45 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
   } else {
     vcmaxcintsha = 0.0;
   }
-  if (!(coszen > 0.0)) {
-    // nothing after init_timestep runs at night except snow_albedo_radiation_factor's "no sun" branch (:758-765)
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++) {
-      LV(albsod, ib) = 0.0;
-      LV(albsoi, ib) = 0.0;
-      LV(albgrd, ib) = 0.0;
-      LV(albgri, ib) = 0.0;
-      LV(albd, ib) = 1.0;
-      LV(albi, ib) = 1.0;
-      LV(fabd, ib) = 0.0;
-      LV(fabi, ib) = 0.0;
-      LV(fabi_sun, ib) = 0.0;
-      LV(fabi_sha, ib) = 0.0;
-      LV(ftdd, ib) = 0.0;
-      LV(ftid, ib) = 0.0;
-      LV(ftii, ib) = 0.0;
-      LV(albsnd, ib) = 0.0;
-      LV(albsni, ib) = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      LV(flx_absdv, i) = 0.0;
-      LV(flx_absdn, i) = 0.0;
-      LV(flx_absiv, i) = 0.0;
-      LV(flx_absin, i) = 0.0;
-    }
-    S->vcmaxcintsun[c] = vcmaxcintsun;
-    S->vcmaxcintsha[c] = vcmaxcintsha;
-    S->fsun_z[c] = 0.0;
-    S->fabd_sun_z[c] = 0.0;
-    S->fabd_sha_z[c] = 0.0;
-    S->fabi_sun_z[c] = 0.0;
-    S->fabi_sha_z[c] = 0.0;
-    return;
-  }
-  const double h2osno = S->h2osno[c];
-  const double albsod[2] = {LV(albsod, 0), LV(albsod, 1)};  // written by stage 1
-  const double albsoi[2] = {LV(albsoi, 0), LV(albsoi, 1)};
+  const bool day = coszen > 0.0;  // nothing after init_timestep runs without sun except snow_albedo_radiation_factor's
+                                  // "no sun" branch (:758-765): alb_finish stores those values for the dark lanes
+  double albsod[2] = {0.0, 0.0}, albsoi[2] = {0.0, 0.0};
+  double esai = 0.0, frac_sno = 0.0;
   SnowOut sd, si;
-  if (h2osno > SN_MIN_SNW) {
-    const double* __restrict__ o = S->alb_snow + c;
-    sd.alb[0] = o[0];
-    sd.alb[1] = o[ld];
-    si.alb[0] = o[(int64_t)14 * ld];
-    si.alb[1] = o[(int64_t)15 * ld];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      sd.fabs_[i][0] = o[(int64_t)(2 + 2 * i) * ld];
-      sd.fabs_[i][1] = o[(int64_t)(3 + 2 * i) * ld];
-      si.fabs_[i][0] = o[(int64_t)(16 + 2 * i) * ld];
-      si.fabs_[i][1] = o[(int64_t)(17 + 2 * i) * ld];
-    }
-  } else {
-    // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
+  for (int i = 0; i < 6; i++) {
+    sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
+    si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
+  }
+  sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
+  if (day) {
+    esai = S->esai[c];
+    frac_sno = S->frac_sno[c];
+    const double h2osno = S->h2osno[c];
+    albsod[0] = LV(albsod, 0);  // written by stage 1
+    albsod[1] = LV(albsod, 1);
+    albsoi[0] = LV(albsoi, 0);
+    albsoi[1] = LV(albsoi, 1);
+    if (h2osno > SN_MIN_SNW) {
+      const double* __restrict__ o = S->alb_snow + c;
+      sd.alb[0] = o[0];
+      sd.alb[1] = o[ld];
+      si.alb[0] = o[(int64_t)14 * ld];
+      si.alb[1] = o[(int64_t)15 * ld];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
-      si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
-    }
-    if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
+      for (int i = 0; i < 6; i++) {
+        sd.fabs_[i][0] = o[(int64_t)(2 + 2 * i) * ld];
+        sd.fabs_[i][1] = o[(int64_t)(3 + 2 * i) * ld];
+        si.fabs_[i][0] = o[(int64_t)(16 + 2 * i) * ld];
+        si.fabs_[i][1] = o[(int64_t)(17 + 2 * i) * ld];
+      }
+    } else if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
+      // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
       sd.alb[0] = si.alb[0] = albsoi[0];
       sd.alb[1] = si.alb[1] = albsoi[1];
-    } else {
-      sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
     }
   }
-  alb_finish(S, c, ld, L, coszen, elai, S->esai[c], S->frac_sno[c], albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
+  alb_finish(S, c, ld, L, day, coszen, elai, esai, frac_sno, albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
 }
 
 __global__ void k_alb_reset(const DevState* __restrict__ S)

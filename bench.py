@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--no-other-tier", action="store_true", help="skip the secondary measurement on the other tier")
     ap.add_argument("--seed", type=int, default=0x5EEDE1A0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the seven wrappers as one captured HIP graph (elmk_set_graph): removes host launch latency, "
+                         "which dominates below ~100k columns")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the per-kernel HIP-event profile")
     args = ap.parse_args()
 
@@ -231,6 +234,8 @@ def main():
         return D, host_state
 
     D, host_state = prepared(args.tier)
+    if args.graph and not soil:
+        D.set_graph(True)
 
     def sync_all():
         D.sync()
@@ -255,6 +260,8 @@ def main():
         D = None
         ot = "B" if args.tier == "A" else "A"
         D2, _ = prepared(ot)
+        if args.graph and not soil:
+            D2.set_graph(True)
 
         def sync2():
             D2.sync()

@@ -64,6 +64,12 @@ struct elmk_ctx {
   std::vector<char*> snap_bufs;
   uint32_t* red_or = nullptr;  // device scalars for elmk_error_summary
   long long* red_first = nullptr;
+  // elmk_set_graph: the seven wrappers of elmk_timestep7 captured once as a HIP graph (kernel nodes + the side-stream
+  // fork / join of albedo_snicar) and replayed; key = (dt, stream)
+  bool use_graph = false;
+  hipGraphExec_t ts7_exec = nullptr;
+  double ts7_dt = 0.0;
+  hipStream_t ts7_stream = nullptr;
   std::string err;
 };
 
@@ -251,6 +257,7 @@ int elmk_destroy(elmk_ctx* ctx)
   if (ctx->snicar) (void)hipFree(ctx->snicar);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d) (void)hipFree(ctx->d);
+  if (ctx->ts7_exec) (void)hipGraphExecDestroy(ctx->ts7_exec);
   if (ctx->red_or) (void)hipFree(ctx->red_or);
   if (ctx->staging) (void)hipFree(ctx->staging);
   for (char* b : ctx->snap_bufs) (void)hipFree(b);
@@ -274,6 +281,18 @@ int elmk_set_stream(elmk_ctx* ctx, void* hip_stream)
   if (int rc = enter(ctx)) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return ELMK_OK;
+}
+
+int elmk_set_graph(elmk_ctx* ctx, int on)
+{
+  if (int rc = enter(ctx)) return rc;
+  ctx->use_graph = on != 0;
+  if (!ctx->use_graph && ctx->ts7_exec) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipGraphExecDestroy(ctx->ts7_exec);
+    ctx->ts7_exec = nullptr;
+  }
   return ELMK_OK;
 }
 
@@ -627,9 +646,46 @@ int elmk_evaluate_conservation(elmk_ctx* ctx, double dt, double* min_max_sum, do
 }
 
 // ELMInterface::advance order (elm_kokkos_interface.cc:289-307)
+namespace {
+void enqueue_timestep7(elmk_ctx* ctx, double dt)
+{
+  launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
+  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
+  launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
+  launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
+  launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
+  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+}
+}  // namespace
+
 int elmk_timestep7(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
+  if (ctx->use_graph) {
+    // ~22 dependent launches cost ~0.5 ms of launch latency however few columns there are; replaying them as one graph
+    // removes the host side of that.  Kernel arguments are the device parameter block (fixed address) and dt.
+    if (!ctx->ts7_exec || ctx->ts7_dt != dt || ctx->ts7_stream != ctx->stream) {
+      if (ctx->ts7_exec) {
+        (void)hipGraphExecDestroy(ctx->ts7_exec);
+        ctx->ts7_exec = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      enqueue_timestep7(ctx, dt);
+      if (hip_fail(ctx, hipStreamEndCapture(ctx->stream, &g), "hipStreamEndCapture")) return ELMK_E_HIP;
+      const hipError_t e = hipGraphInstantiate(&ctx->ts7_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (hip_fail(ctx, e, "hipGraphInstantiate")) {
+        ctx->ts7_exec = nullptr;
+        return ELMK_E_HIP;
+      }
+      ctx->ts7_dt = dt;
+      ctx->ts7_stream = ctx->stream;
+    }
+    HIPCHK(hipGraphLaunch(ctx->ts7_exec, ctx->stream));
+    return ELMK_OK;
+  }
   launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
   launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
   launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);

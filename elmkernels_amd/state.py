@@ -218,6 +218,10 @@ class ELMState:
         self._chk(self.lib.elmk_profile_wrapper(self.ctx, int(wrapper), float(dt), int(nsteps), C.byref(ms)), "profile_wrapper")
         return ms.value
 
+    def set_graph(self, on=True):
+        """timestep7 as one replayed HIP graph (elmk_set_graph)."""
+        self._chk(self.lib.elmk_set_graph(self.ctx, int(bool(on))), "set_graph")
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=20):
         g = C.c_double()
         self._chk(self.lib.elmk_copy_bandwidth(self.ctx, int(nbytes), int(iters), C.byref(g)), "copy_bandwidth")

@@ -143,6 +143,10 @@ int elmk_destroy(elmk_ctx *ctx);
 const char *elmk_last_error(const elmk_ctx *ctx); /* ctx may be NULL: error of the last failed create */
 int elmk_set_stream(elmk_ctx *ctx, void *hip_stream); /* hipStream_t; NULL restores the context's own stream */
 int elmk_sync(elmk_ctx *ctx);
+/* on != 0: elmk_timestep7 captures its ~22 kernel launches (and the side-stream fork / join inside albedo_snicar) once as
+ * a HIP graph and replays it on every call with the same dt and stream.  Same kernels, same order, same results; what
+ * it removes is per-launch host latency, which is all there is to a step of a few thousand columns. */
+int elmk_set_graph(elmk_ctx *ctx, int on);
 int64_t elmk_ncols(const elmk_ctx *ctx);
 int64_t elmk_level_stride(const elmk_ctx *ctx); /* elements between consecutive levels of a device field */
 int64_t elmk_device_bytes(const elmk_ctx *ctx);

@@ -358,6 +358,28 @@ def test_init_timestep_column_kernel():
     D.close()
 
 
+def test_graph_replay_is_the_same_step():
+    """elmk_set_graph: timestep7 captured once and replayed as a HIP graph (side-stream fork / join included) gives the same
+    bits as the launch-by-launch step, step after step, also after a change of dt (re-capture) and when switched off."""
+    n = 5000
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier="B", seed=81)
+    A = H.device_state(cols, scal, soil)
+    B = H.device_state(cols, scal, soil)
+    B.set_graph(True)
+    for dt in (DT, DT, 900.0, DT):
+        st.timestep7(A, dt)
+        st.timestep7(B, dt)
+        for k in A.fields:
+            assert np.array_equal(A[k], B[k], equal_nan=True), (dt, k)
+    B.set_graph(False)
+    st.timestep7(A, DT)
+    st.timestep7(B, DT)
+    assert all(np.array_equal(A[k], B[k], equal_nan=True) for k in A.fields)
+    A.close()
+    B.close()
+
+
 def test_get_forcing_and_phenology():
     """The per-column functors kokkos_init_timestep runs first - get_forcing's eight ComputeAtmForcing_* functors (specific-
     and relative-humidity streams) and ComputePhenology - on records / months on both sides of every clamp: every field

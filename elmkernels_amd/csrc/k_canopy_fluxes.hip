@@ -65,6 +65,9 @@ struct PsnInv {
   double vcmaxse, jmaxse, tpuse, vcmaxc, jmaxc, tpuc, lmrc;
   double cf, kc25, ko25, cp25;
   double qe, theta_cj, bbbopt, mbbopt;
+  // activation / deactivation energies and entropy terms of the column's PFT, read per trip by psn_temp: kept in
+  // registers, so that a trip issues no global load at all
+  double lmrha, lmrhd, lmrse, vcmaxha, vcmaxhd, jmaxha, jmaxhd, tpuha, tpuhd, kcha, koha, cpha;
 };
 
 // per-trip temperature factors shared by the sunlit and shaded call
@@ -241,27 +244,27 @@ __device__ __forceinline__ PsnTemp psn_temp(const PsnInv& I, const double* __res
   T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
   T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
   if (I.c3flag) {
-    T.ft_lmr = psn_ft(t_veg, P[P_lmrha]);
-    T.fth_lmr = psn_fth(t_veg, P[P_lmrhd], P[P_lmrse], I.lmrc);
+    T.ft_lmr = psn_ft(t_veg, I.lmrha);
+    T.fth_lmr = psn_fth(t_veg, I.lmrhd, I.lmrse, I.lmrc);
   } else {
     T.p2 = elmk_pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
     T.e_lmr_c4 = elmk_exp(1.3 * (t_veg - (TFRZ + 55.0)));
   }
   if (day) {
     if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
-      T.ft_vcmax = psn_ft(t_veg, P[P_vcmaxha]);
-      T.fth_vcmax = psn_fth(t_veg, P[P_vcmaxhd], I.vcmaxse, I.vcmaxc);
+      T.ft_vcmax = psn_ft(t_veg, I.vcmaxha);
+      T.fth_vcmax = psn_fth(t_veg, I.vcmaxhd, I.vcmaxse, I.vcmaxc);
     } else {
       T.e_vc4a = elmk_exp(0.2 * ((TFRZ + 15.0) - t_veg));
       T.e_vc4b = elmk_exp(0.3 * (t_veg - (TFRZ + 40.0)));
     }
-    T.ft_jmax = psn_ft(t_veg, P[P_jmaxha]);
-    T.fth_jmax = psn_fth(t_veg, P[P_jmaxhd], I.jmaxse, I.jmaxc);
-    T.ft_tpu = psn_ft(t_veg, P[P_tpuha]);
-    T.fth_tpu = psn_fth(t_veg, P[P_tpuhd], I.tpuse, I.tpuc);
-    T.kc = I.kc25 * psn_ft(t_veg, P[P_kcha]);
-    T.ko = I.ko25 * psn_ft(t_veg, P[P_koha]);
-    T.cp = I.cp25 * psn_ft(t_veg, P[P_cpha]);
+    T.ft_jmax = psn_ft(t_veg, I.jmaxha);
+    T.fth_jmax = psn_fth(t_veg, I.jmaxhd, I.jmaxse, I.jmaxc);
+    T.ft_tpu = psn_ft(t_veg, I.tpuha);
+    T.fth_tpu = psn_fth(t_veg, I.tpuhd, I.tpuse, I.tpuc);
+    T.kc = I.kc25 * psn_ft(t_veg, I.kcha);
+    T.ko = I.ko25 * psn_ft(t_veg, I.koha);
+    T.cp = I.cp25 * psn_ft(t_veg, I.cpha);
   }
   return T;
 }
@@ -878,6 +881,18 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       forc_pco2 = derive_forc_pco2(in.forc_pbot);
       zldis = in.hgt_u - in.displa;
       I.c3flag = (round(P[P_c3psn]) == 1);
+      I.lmrha = P[P_lmrha];
+      I.lmrhd = P[P_lmrhd];
+      I.lmrse = P[P_lmrse];
+      I.vcmaxha = P[P_vcmaxha];
+      I.vcmaxhd = P[P_vcmaxhd];
+      I.jmaxha = P[P_jmaxha];
+      I.jmaxhd = P[P_jmaxhd];
+      I.tpuha = P[P_tpuha];
+      I.tpuhd = P[P_tpuhd];
+      I.kcha = P[P_kcha];
+      I.koha = P[P_koha];
+      I.cpha = P[P_cpha];
       I.vcmax25top = in.vcmax25top;
       I.jmax25top = in.jmax25top;
       I.tpu25top = in.tpu25top;

@@ -156,7 +156,8 @@ ELMK_MFN double elmk_exp_core(double x, double xtail, uint32_t sign_bias, int wi
 }
 
 // ---- exp: glibc 2.35 sysdeps/ieee754/dbl-64/e_exp.c (__exp_fma) -------------------------------------------------------
-ELMK_MFN double elmk_exp(double x)
+// every case, in the source's control flow
+ELMK_MFN double elmk_exp_general(double x)
 {
   const uint64_t ix = elmk_asu64(x);
   const uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ff;
@@ -167,42 +168,73 @@ ELMK_MFN double elmk_exp(double x)
   }
   return elmk_exp_core(x, 0.0, 0, 0);
 }
+// The function the kernels call.  Same bits; different shape: the main path (2^-54 <= |x| < 512) is evaluated
+// unconditionally as ONE straight-line block and everything else is a single, rarely taken branch afterwards.  The
+// source's nest of range checks costs a wave that runs alone on its SIMD four exec-mask save / restore sequences per
+// call and keeps the scheduler from overlapping the table read with the argument reduction: 197 -> ~90 ns per call in
+// a dependent chain (tests/tools/ubench/math_issue.hip).
+ELMK_MFN double elmk_exp(double x)
+{
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const uint32_t abstop = (uint32_t)(elmk_asu64(x) >> 52) & 0x7ff;
+  double kd = ELMK_FMA(x, InvLn2N, Shift);
+  const uint64_t ki = elmk_asu64(kd);
+  kd -= Shift;
+  double r = ELMK_FMA(kd, NegLn2hiN, x);
+  r = ELMK_FMA(kd, NegLn2loN, r);
+  const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+  const double tail = elmk_asf64(ELMK_T_EXP[idx]);
+  const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45);
+  const double tmp = elmk_exp_poly(r, tail);
+  const double scale = elmk_asf64(sbits);
+  double y = ELMK_FMA(scale, tmp, scale);
+  if (__builtin_expect(abstop - 0x3c9u >= 0x3fu, 0)) y = elmk_exp_general(x);
+  return y;
+}
 
 // ---- log: glibc 2.35 sysdeps/ieee754/dbl-64/e_log.c (__log_fma) -------------------------------------------------------
-ELMK_MFN double elmk_log(double x)
+// log for 1 - 2^-4 <= x < 1 + 0x1.09p-4 (e_log.c's "close to 1.0" polynomial), straight-line; x == 1 gives +0 as the
+// source's explicit test does
+ELMK_MFN double elmk_log_near1(double x)
+{
+  const double B0 = -0x1p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3,
+               B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de3p-3, B6 = -0x1.fffffa4423d65p-4,
+               B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4, B9 = 0x1.78182f7afd085p-4,
+               B10 = -0x1.5521375d145cdp-4;
+  const double r = x - 1.0;
+  double p1 = ELMK_FMA(r, B2, B1);
+  double p4 = ELMK_FMA(r, B5, B4);
+  const double r2 = r * r;
+  double p7 = ELMK_FMA(r, B8, B7);
+  p1 = ELMK_FMA(r2, B3, p1);
+  p4 = ELMK_FMA(r2, B6, p4);
+  const double r3 = r * r2;
+  p7 = ELMK_FMA(r2, B9, p7);
+  p7 = ELMK_FMA(r3, B10, p7);
+  p4 = ELMK_FMA(p7, r3, p4);
+  p1 = ELMK_FMA(p4, r3, p1);
+  const double t = ELMK_FMA(r, 0x1p27, r);
+  const double rhi = ELMK_FMA(-0x1p27, r, t);
+  const double rhi2 = rhi * rhi;
+  const double rlo = r - rhi;
+  const double hi = ELMK_FMA(rhi2, B0, r);
+  const double t8 = r - hi;
+  const double s = r + rhi;
+  double lo = ELMK_FMA(rhi2, B0, t8);
+  const double u = B0 * rlo;
+  lo = ELMK_FMA(u, s, lo);
+  const double y = ELMK_FMA(p1, r3, lo);
+  return hi + y;
+}
+
+ELMK_MFN double elmk_log_general(double x)
 {
   uint64_t ix = elmk_asu64(x);
   const uint32_t top = (uint32_t)(ix >> 48);
   if (ix - 0x3fee000000000000ull < 0x3090000000000ull) {  // 1 - 2^-4 <= x < 1 + 0x1.09p-4
     if (ix == 0x3ff0000000000000ull) return 0.0;
-    const double B0 = -0x1p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3, B3 = 0x1.999999995dd0cp-3,
-                 B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de3p-3, B6 = -0x1.fffffa4423d65p-4,
-                 B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4, B9 = 0x1.78182f7afd085p-4,
-                 B10 = -0x1.5521375d145cdp-4;
-    const double r = x - 1.0;
-    double p1 = ELMK_FMA(r, B2, B1);
-    double p4 = ELMK_FMA(r, B5, B4);
-    const double r2 = r * r;
-    double p7 = ELMK_FMA(r, B8, B7);
-    p1 = ELMK_FMA(r2, B3, p1);
-    p4 = ELMK_FMA(r2, B6, p4);
-    const double r3 = r * r2;
-    p7 = ELMK_FMA(r2, B9, p7);
-    p7 = ELMK_FMA(r3, B10, p7);
-    p4 = ELMK_FMA(p7, r3, p4);
-    p1 = ELMK_FMA(p4, r3, p1);
-    const double t = ELMK_FMA(r, 0x1p27, r);
-    const double rhi = ELMK_FMA(-0x1p27, r, t);
-    const double rhi2 = rhi * rhi;
-    const double rlo = r - rhi;
-    const double hi = ELMK_FMA(rhi2, B0, r);
-    const double t8 = r - hi;
-    const double s = r + rhi;
-    double lo = ELMK_FMA(rhi2, B0, t8);
-    const double u = B0 * rlo;
-    lo = ELMK_FMA(u, s, lo);
-    const double y = ELMK_FMA(p1, r3, lo);
-    return hi + y;
+    return elmk_log_near1(x);
   }
   if (top - 0x0010u >= 0x7ff0u - 0x0010u) {  // x < 2^-1022, inf or nan
     if (ix * 2 == 0) return -ELMK_INF;
@@ -216,7 +248,7 @@ ELMK_MFN double elmk_log(double x)
                A4 = -0x1.55575e506c89fp-3;
   const uint64_t tmp = ix - 0x3fe6000000000000ull;
   const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
-  const int k = (int)((int64_t)tmp >> 52);
+  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // (int64_t)tmp >> 52, from the high word
   const uint64_t iz = ix - (tmp & 0xfffull << 52);
   const double invc = elmk_asf64(ELMK_T_LOG[2 * i]), logc = elmk_asf64(ELMK_T_LOG[2 * i + 1]);
   const double z = elmk_asf64(iz);
@@ -235,6 +267,41 @@ ELMK_MFN double elmk_log(double x)
   p34 = ELMK_FMA(p34, r2, p12);
   const double y = ELMK_FMA(r3, p34, lo);
   return y + hi;
+}
+
+// The function the kernels call: same bits; the table path (positive normal x outside [1 - 2^-4, 1 + 0x1.09p-4)) is one
+// straight-line block with a single rarely taken branch behind it for zero / negative / subnormal / inf / nan; the
+// near-1 polynomial stays a branch of its own (evaluating both and selecting was measured: 191 -> 236 ns per call).
+ELMK_MFN double elmk_log(double x)
+{
+  const uint64_t ix = elmk_asu64(x);
+  if (ix - 0x3fee000000000000ull < 0x3090000000000ull) return elmk_log_general(x);  // near 1: its own polynomial
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb459p-3, A3 = 0x1.999b324f10111p-3,
+               A4 = -0x1.55575e506c89fp-3;
+  const uint32_t top = (uint32_t)(ix >> 48);
+  const uint64_t tmp = ix - 0x3fe6000000000000ull;
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // (int64_t)tmp >> 52, from the high word
+  const uint64_t iz = ix - (tmp & 0xfffull << 52);
+  const double invc = elmk_asf64(ELMK_T_LOG[2 * i]), logc = elmk_asf64(ELMK_T_LOG[2 * i + 1]);
+  const double z = elmk_asf64(iz);
+  const double kd = (double)k;
+  const double r = ELMK_FMA(z, invc, -1.0);
+  const double w = ELMK_FMA(kd, Ln2hi, logc);
+  const double p12 = ELMK_FMA(r, A2, A1);
+  const double hi = w + r;
+  const double r2 = r * r;
+  double lo = w - hi;
+  lo = lo + r;
+  lo = ELMK_FMA(kd, Ln2lo, lo);
+  const double r3 = r * r2;
+  double p34 = ELMK_FMA(r, A4, A3);
+  lo = ELMK_FMA(r2, A0, lo);
+  p34 = ELMK_FMA(p34, r2, p12);
+  double y = ELMK_FMA(r3, p34, lo) + hi;
+  if (__builtin_expect(top - 0x0010u >= 0x7ff0u - 0x0010u, 0)) y = elmk_log_general(x);
+  return y;
 }
 
 // ---- log10: glibc 2.35 sysdeps/ieee754/dbl-64/e_log10.c (fdlibm scaling around __ieee754_log; no FMA build) ------------
@@ -277,7 +344,7 @@ ELMK_MFN int elmk_checkint(uint64_t iy)
 }
 ELMK_MFN int elmk_zeroinfnan(uint64_t i) { return 2 * i - 1 >= 2 * 0x7ff0000000000000ull - 1; }
 
-ELMK_MFN double elmk_pow(double x, double y)
+ELMK_MFN double elmk_pow_general(double x, double y)
 {
   uint32_t sign_bias = 0;
   uint64_t ix = elmk_asu64(x);
@@ -323,7 +390,7 @@ ELMK_MFN double elmk_pow(double x, double y)
                A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p0, A6 = 0x1.0002b8b263fc3p0;
   const uint64_t tmp = ix - 0x3fe6955500000000ull;
   const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
-  const int k = (int)((int64_t)tmp >> 52);
+  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // (int64_t)tmp >> 52, from the high word
   const uint64_t iz = ix - (tmp & 0xfffull << 52);
   const double z = elmk_asf64(iz);
   const double kd = (double)k;
@@ -356,6 +423,71 @@ ELMK_MFN double elmk_pow(double x, double y)
   double elo = ELMK_FMA(lhi, y, -ehi);
   elo = ELMK_FMA(y, llo, elo);
   return elmk_exp_core(ehi, elo, sign_bias, 1);
+}
+
+// The function the kernels call: same bits; for positive normal x, 2^-65 <= |y| < 2^63 and 2^-54 <= |y log x| < 512 -
+// everything the physics does - log_inline and exp_inline run as one straight-line block; any other argument takes the
+// single branch to the general form afterwards.
+ELMK_MFN double elmk_pow(double x, double y)
+{
+  const uint64_t ix = elmk_asu64(x);
+  const uint32_t topx = (uint32_t)(ix >> 52);
+  const uint32_t topy = (uint32_t)(elmk_asu64(y) >> 52);
+  const int rare_arg = (topx - 0x001u >= 0x7ffu - 0x001u) | ((topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu);
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A0 = -0x1p-1, A1 = -0x1.555555555556p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
+               A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p0, A6 = 0x1.0002b8b263fc3p0;
+  const uint64_t tmp = ix - 0x3fe6955500000000ull;
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // (int64_t)tmp >> 52, from the high word
+  const uint64_t iz = ix - (tmp & 0xfffull << 52);
+  const double z = elmk_asf64(iz);
+  const double kd = (double)k;
+  const double invc = elmk_asf64(ELMK_T_POWLOG[3 * i]), logc = elmk_asf64(ELMK_T_POWLOG[3 * i + 1]),
+               logctail = elmk_asf64(ELMK_T_POWLOG[3 * i + 2]);
+  const double r = ELMK_FMA(z, invc, -1.0);
+  const double t1 = ELMK_FMA(kd, Ln2hi, logc);
+  const double t2 = t1 + r;
+  const double lo1 = ELMK_FMA(kd, Ln2lo, logctail);
+  const double lo2 = t1 - t2 + r;
+  const double ar = A0 * r;
+  const double ar2 = r * ar;
+  const double ar3 = r * ar2;
+  const double hi = t2 + ar2;
+  const double lo3 = ELMK_FMA(ar, r, -ar2);
+  const double lo4 = t2 - hi + ar2;
+  const double p12 = ELMK_FMA(r, A2, A1);
+  const double p34 = ELMK_FMA(r, A4, A3);
+  double p = ELMK_FMA(r, A6, A5);
+  p = ELMK_FMA(p, ar2, p34);
+  p = ELMK_FMA(ar2, p, p12);
+  double lo = lo1 + lo2;
+  lo = lo + lo3;
+  lo = lo + lo4;
+  lo = ELMK_FMA(p, ar3, lo);
+  const double lhi = hi + lo;
+  const double llo = hi - lhi + lo;
+  const double ehi = y * lhi;
+  double elo = ELMK_FMA(lhi, y, -ehi);
+  elo = ELMK_FMA(y, llo, elo);
+  // exp_inline, main path
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const uint32_t abstop = (uint32_t)(elmk_asu64(ehi) >> 52) & 0x7ff;
+  double ekd = ELMK_FMA(ehi, InvLn2N, Shift);
+  const uint64_t ki = elmk_asu64(ekd);
+  ekd -= Shift;
+  double er = ELMK_FMA(ekd, NegLn2hiN, ehi);
+  er = ELMK_FMA(ekd, NegLn2loN, er);
+  er = elo + er;
+  const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+  const double tail = elmk_asf64(ELMK_T_EXP[idx]);
+  const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45);
+  const double etmp = elmk_exp_poly(er, tail);
+  const double scale = elmk_asf64(sbits);
+  double res = ELMK_FMA(scale, etmp, scale);
+  if (__builtin_expect(rare_arg | (abstop - 0x3c9u >= 0x3fu), 0)) res = elmk_pow_general(x, y);
+  return res;
 }
 
 // ---- atan: glibc 2.35 sysdeps/ieee754/dbl-64/s_atan.c (__atan_fma; IBM Accurate Mathematical Library, the version with

@@ -390,6 +390,7 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
 #define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
 #endif
 constexpr int CF_REFILL_MIN = 8;
+constexpr int CF_BLOCK_EXTRA = 24;  // queue positions a wave claims beyond what a refill needs (its private block)
 
 // doubles of a queue record (k_cf_init -> k_cf_iterate)
 #define CF_REC_FIELDS(X)                                                                                               \
@@ -811,6 +812,9 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   bool exhausted = false;  // wave-uniform: the queue is empty
   int64_t pos = -1;        // queue position owned by this lane (-1: idle)
   bool fresh = false;      // the lane has just received a position and must load its record
+  uint32_t blk_next = 0, blk_end = 0;  // wave-uniform: the wave's private block of claimed queue positions
+  uint32_t last_base = 0;              // queue head as this wave last saw it
+  const uint32_t nwaves_total = gridDim.x * (blockDim.x >> 6);
 
   CfRec in;
   PsnInv I;
@@ -848,19 +852,40 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
     // Idle lanes are refilled in batches (>= CF_REFILL_MIN of them, which includes the all-idle wave) with one
     // wave-aggregated atomic on the queue head.
     const int nidle = __popcll(__ballot(pos < 0));
-    if (!exhausted && nidle >= CF_REFILL_MIN) {
+    if (nidle >= CF_REFILL_MIN && (!exhausted || blk_next < blk_end)) {
       const bool take = (pos < 0);
       const unsigned long long m = __ballot(take);
-      const int leader = __ffsll((long long)m) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE), (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
-      const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (take && mine < nq) {
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      // positions come from the wave's private block first; one atomic on the queue head claims the next block
+      // (what this refill still needs + CF_BLOCK_EXTRA for the refills to come): the atomic's round trip is then
+      // paid by one refill in three or four instead of by every one
+      const uint32_t have = blk_end - blk_next;
+      uint32_t mine = 0xffffffffu;
+      if (rank < have) mine = blk_next + rank;
+      blk_next += ((uint32_t)nidle < have) ? (uint32_t)nidle : have;
+      if ((uint32_t)nidle > have && !exhausted) {
+        const uint32_t need = (uint32_t)nidle - have;
+        // no hoarding near the end of the queue: with fewer than CF_BLOCK_EXTRA positions per wave left, claim exactly
+        const uint32_t extra = (nq - last_base > (uint32_t)CF_BLOCK_EXTRA * nwaves_total) ? (uint32_t)CF_BLOCK_EXTRA : 0u;
+        const uint32_t want = need + extra;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE), want);
+        base = __shfl(base, 0, 64);
+        last_base = (base < nq) ? base : nq;
+        const uint32_t b1 = (base + want < nq) ? base + want : nq;
+        const uint32_t b0 = (base < b1) ? base : b1;
+        if (base + want >= nq) exhausted = true;
+        if (take && rank >= have) {
+          const uint32_t p = b0 + (rank - have);
+          if (p < b1) mine = p;
+        }
+        blk_next = (b0 + need < b1) ? b0 + need : b1;
+        blk_end = b1;
+      }
+      if (take && mine != 0xffffffffu) {
         pos = (int64_t)mine;
         fresh = true;
       }
-      if (base + (uint32_t)__popcll(m) >= nq) exhausted = true;
 #if CF_PROBE >= 4
       pr_refills++;
       if (exhausted && !pr_texh) pr_texh = wall_clock64();
@@ -935,7 +960,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       eflx_sh_veg = 0.0;
     }
     if (__ballot(pos >= 0) == 0ull) {
-      if (exhausted) break;
+      if (exhausted && blk_next >= blk_end) break;
       continue;
     }
     PR_T(0)

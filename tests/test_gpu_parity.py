@@ -358,6 +358,18 @@ def test_init_timestep_column_kernel():
     D.close()
 
 
+def test_empty_state():
+    """Zero columns (a rank that owns nothing after the block split): every entry is a no-op that succeeds."""
+    D = st.ELMState(0)
+    st.kokkos_init_timestep(D)
+    st.timestep7(D, DT)
+    st.kokkos_soil_temperature(D, DT)
+    st.kokkos_surface_fluxes(D, DT)
+    assert D.error_summary() == (0, -1)
+    assert D.download("t_soisno").shape == (0, 20)
+    D.close()
+
+
 def test_graph_replay_is_the_same_step():
     """elmk_set_graph: timestep7 captured once and replayed as a HIP graph (side-stream fork / join included) gives the same
     bits as the launch-by-launch step, step after step, also after a change of dt (re-capture) and when switched off."""

@@ -24,6 +24,12 @@ __global__ __launch_bounds__(256) void k(double* out, double a, int iters)
         if (OP == 4) x[j] = exp(x[j] * 1e-3) + 0.5;
         if (OP == 5) x[j] = log(x[j] + 1.5) + 2.0;
         if (OP == 6) x[j] = pow(x[j], 0.333) + 1.0;
+        if (OP == 9) x[j] = elmk_erf(x[j] * 0.3) + 1.0;
+        if (OP == 10) x[j] = erf(x[j] * 0.3) + 1.0;
+        if (OP == 11) x[j] = elmk_tanh(x[j] * 0.3) + 1.0;
+        if (OP == 12) x[j] = tanh(x[j] * 0.3) + 1.0;
+        if (OP == 13) x[j] = elmk_cos(x[j]) + 1.5;
+        if (OP == 14) x[j] = cos(x[j]) + 1.5;
         if (OP == 7) x[j] = elmk_log(x[j] * 1e-3 + 1.0) + 2.0;  // arguments near 1
         if (OP == 8) x[j] = log(x[j] * 1e-3 + 1.0) + 2.0;
       }
@@ -60,5 +66,7 @@ int main()
   run<1, 7>("elmk_log~1", d); run<4, 7>("elmk_log~1", d); run<1, 8>("ocml log~1", d);
   run<1, 2>("elmk_pow", d); run<4, 2>("elmk_pow", d); run<1, 6>("ocml pow", d); run<4, 6>("ocml pow", d);
   run<1, 3>("elmk_atan", d); run<4, 3>("elmk_atan", d);
+  run<1, 9>("elmk_erf", d); run<1, 10>("ocml erf", d); run<1, 11>("elmk_tanh", d); run<1, 12>("ocml tanh", d);
+  run<1, 13>("elmk_cos", d); run<1, 14>("ocml cos", d);
   return 0;
 }

@@ -496,7 +496,7 @@ ELMK_MFN double elmk_atan_signed(double y, double x)  // |y| with the sign of x
 {
   return elmk_asf64((elmk_asu64(y) & 0x7fffffffffffffffull) | (elmk_asu64(x) & 0x8000000000000000ull));
 }
-ELMK_MFN double elmk_atan(double x)
+ELMK_MFN double elmk_atan_general(double x)
 {
   const double d3 = -0x1.5555555555555p-2, d5 = 0x1.99999999997fdp-3, d7 = -0x1.24924923f7603p-3, d9 = 0x1.c71c6e5129a3bp-4,
                d11 = -0x1.7458022b13c25p-4, d13 = 0x1.375f08b31cbcep-4;
@@ -579,6 +579,35 @@ ELMK_MFN double elmk_atan(double x)
 // reference's default Debug (-O0) build would return.
 ELMK_MFN double elmk_sq(double x) { return x * x; }
 ELMK_MFN double elmk_pow1(double x) { return x; }
+
+// The function the kernels call: same bits; the 1 <= |x| < 16 range - all the physics asks for (stability function of the
+// unstable surface layer, chi = (1 - 16 zeta)^(1/4) with -100 <= zeta < 0) - as one straight-line block, any other argument
+// through the single branch to the general form.
+ELMK_MFN double elmk_atan(double x)
+{
+  const double HPI = 0x1.921fb54442d18p+0, HPI1 = 0x1.1a62633145c07p-54;
+  const double u = __builtin_fabs(x);
+  const double w = 1.0 / u;
+  const double t1 = u * w;
+  const double a = 1.0 - t1;
+  const double t2 = ELMK_FMA(u, w, -t1);
+  int i = (int)(ELMK_FMA(w, 256.0, 0x1p52) - 0x1p52) - 16;
+  i = (i < 0) ? 0 : ((i > 240) ? 240 : i);  // only ever out of range for arguments that take the general form below
+  const uint64_t* c = ELMK_T_ATAN + 7 * i;
+  const double t3 = a - t2;
+  const double zz = w - elmk_asf64(c[0]);
+  const double z = ELMK_FMA(t3, w, zz);
+  double p = elmk_asf64(c[6]);
+  p = ELMK_FMA(z, p, elmk_asf64(c[5]));
+  p = ELMK_FMA(z, p, elmk_asf64(c[4]));
+  p = ELMK_FMA(z, p, elmk_asf64(c[3]));
+  p = ELMK_FMA(z, p, elmk_asf64(c[2]));
+  const double yy = ELMK_FMA(-z, p, HPI1);
+  const double t = HPI - elmk_asf64(c[1]);
+  double y = elmk_atan_signed(t + yy, x);
+  if (__builtin_expect(!(u >= 1.0 && u < 16.0), 0)) y = elmk_atan_general(x);
+  return y;
+}
 
 // ---- expm1, tanh: glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c, s_tanh.c (fdlibm; these have no FMA build on x86-64:
 // plain multiplies and adds in the source's order) ------------------------------------------------------------------------

@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
 """bench.py - gridcell-timesteps/sec of the full water+energy timestep (all 7 kernels) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--cols C] [--tier A|B] [--workload timestep7|soil_temperature]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cols C] [--tier A|B] [--workload timestep7|soil_temperature] [--fused]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  Columns shard halo-free across ranks (elmkernels_amd.decomp: the reference's 1-D block
-split); there is no data-path collective - torch.distributed (RCCL) only carries the barrier and the
-max-over-ranks of the timed region.  Per-GPU work is fixed (weak scaling): --cols columns on every rank.
+One process per GPU.  `python bench.py --gpus N` without a launcher starts the N rank processes itself (the parent never
+touches the GPU and never re-executes: it only spawns children, relays rank 0's line and returns the worst exit code);
+under torch.distributed.run the ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  BASELINE config 4 (80 M columns over
+8 GPUs) is `--gpus 8 --cols 10000000`.
+
+Columns shard halo-free across ranks (elmkernels_amd.decomp: the reference's 1-D block split, src/utils/utils.cc:27-44);
+there is no data-path collective - torch.distributed (RCCL) only carries the barrier and the max-over-ranks of the timed
+region.  Per-GPU work is fixed (weak scaling): --cols columns on every rank.
 
 A "step" = one pass of the reference's ELMInterface::advance hot path over the resident state: restore of the
 snapshot fields (t_veg + forcing heights: what the rest of the model does between steps, 64 B/column), then
 frac_wet -> albedo_snicar -> canopy_hydrology -> surface_radiation -> canopy_temperature -> bareground_fluxes
--> canopy_fluxes, each a hand-written HIP kernel over SoA state in HBM.
+-> canopy_fluxes, each a hand-written HIP kernel over SoA state in HBM (--fused: the same step through
+elmk_timestep7_fused, one streaming stage for the wrappers between albedo and the leaf-temperature iteration).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event
-timed on the launch stream) and `cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+timed on the launch stream), `cpu_baseline` (the C oracle and, where oracle/_ref was built, the reference's own headers,
+both with OpenMP on the host cores, bounded sample) and, at N = 1 on the default workload, `north_star_10M` (the same
+step at the north-star size, 10 M columns, both synthetic tiers).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -34,9 +43,20 @@ ALGO_BYTES = {
     "canopy_temperature": 753, "bareground_fluxes": 368, "canopy_fluxes": 2076,
 }
 ALGO_BYTES_STEP = sum(ALGO_BYTES.values())  # 5281
+ALGO_BYTES_FUSED = 3405  # fused lower bound: every state element read once + written once per step
+# what a predicate-gated wrapper touches on a column it does NOT work on: albedo's init_timestep defaults (500 B written),
+# bareground's cgrnd* reset (24 B), canopy_fluxes' bare branch (32 B)
+GATED_IDLE_BYTES = {"albedo_snicar": 500, "bareground_fluxes": 24, "canopy_fluxes": 32}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 RESTORE_FIELDS = ["t_veg", "forc_hgt_u_patch", "forc_hgt_t_patch", "forc_hgt_q_patch"]
 NBASE = 47 * 64 * 8  # host-generated base block; the device tiles it to --cols
+NORTH_STAR_COLS = 10_000_000
+TIER_NAMES = {"A": "fixture-tiled", "B": "branch-mix"}
+
+# Test hook (tests/test_sharding_gloo.py): a factory that stands in for build_state so that the multi-rank control flow
+# of this file - rank discovery, self-spawn, block split, barrier, max-over-ranks, rank-0 aggregation, the JSON line -
+# runs on CPU under gloo.  "module:function", imported only when the variable is set; the product path never sets it.
+REHEARSAL_ENV = "ELMK_BENCH_REHEARSAL"
 
 
 def build_state(ncols, device, tier, seed):
@@ -62,9 +82,25 @@ def build_state(ncols, device, tier, seed):
     return D, (cols, scal, soil)
 
 
-def cpu_baseline(host_state, budget_s=15.0, workload="timestep7"):
-    """The oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP) on the
-    host cores, on a bounded sample of the same workload."""
+def _timed_loop(fn, budget_s, min_steps=3, max_steps=100000):
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        fn()
+        steps += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and steps >= min_steps) or steps >= max_steps:
+            return steps, el
+
+
+def cpu_baseline(host_state, budget_s=12.0, workload="timestep7"):
+    """The CPU path beside the GPU numbers, on a bounded sample of the same workload (the whole host-generated base block,
+    24 064 columns; every timing covers >= 1 M column-steps so OpenMP fork/join noise stays small):
+      * kind "port": the oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP);
+      * "reference_headers": the reference's OWN physics headers (oracle/_ref/libelmref.so, compiled in the build
+        container) under `#pragma omp parallel for schedule(static)` - the execution shape of
+        Kokkos::parallel_for(RangePolicy<OpenMP>) - for the five wrappers whose headers build without netcdf, with the
+        port timed on the same five beside it."""
     from tests import helpers as H
 
     cols, scal, soil = host_state
@@ -72,78 +108,146 @@ def cpu_baseline(host_state, budget_s=15.0, workload="timestep7"):
 
     threads = O.lib().lib.elmo_get_max_threads()
     nb = next(iter(cols.values())).shape[0]
-    n = min(nb, 24064)
+    n = min(nb, NBASE)
     sub = {k: v[:n] for k, v in cols.items()}
     S = H.oracle_state(sub, scal, soil)
     tveg = S["t_veg"].copy()
     hg = {k: S[k].copy() for k in RESTORE_FIELDS[1:]}
     S.timestep7(1800.0)  # warm-up (thread pool, page faults)
+    min_steps = max(3, -(-1_000_000 // n))
     if workload == "soil_temperature":
         saved = {k: S[k].copy() for k in SOIL_RESTORE}
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        if workload == "soil_temperature":
+
+        def step():
             for k, v in saved.items():
                 S[k][...] = v
             S.soil_temperature(1800.0)
-        else:
+    else:
+        def step():
             S["t_veg"][:] = tveg
             for k, v in hg.items():
                 S[k][:] = v
             S.timestep7(1800.0)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or steps >= 5000:
-            break
-    return {
+    steps, el = _timed_loop(step, budget_s, min_steps)
+    out = {
         "value": n * steps / el, "unit": "gridcell-timesteps/s", "cores": int(threads), "kind": "port",
         "sample": f"{n} columns x {steps} timesteps of the same tier, oracle/libelmoracle.so (gcc -O2 -fopenmp), {el:.1f} s",
     }
+    if workload != "timestep7" or not O.have_ref():
+        return out
+    # the five wrappers the reference's headers cover, in advance() order, reference and port on identical inputs
+    R = O.Reference()
+    rthreads = int(R.R.elmref_max_threads()) if hasattr(R.R, "elmref_max_threads") else 1
+    base = S.clone()
+
+    def five(run):
+        def f():
+            S.copy_from(base)
+            run()
+        return f
+
+    def ref5():
+        R.frac_wet(S)
+        R.canopy_hydrology(S, 1800.0)
+        R.surface_radiation(S)
+        R.canopy_temperature(S)
+        R.bareground_fluxes(S)
+
+    def port5():
+        S.frac_wet()
+        S.canopy_hydrology(1800.0)
+        S.surface_radiation()
+        S.canopy_temperature()
+        S.bareground_fluxes()
+
+    # the state copy between passes is timed separately and subtracted (it is part of neither path)
+    cs, ce = _timed_loop(lambda: S.copy_from(base), 1.0, 5)
+    copy_s = ce / cs
+    rs, re_ = _timed_loop(five(ref5), 4.0, min_steps)
+    ps, pe = _timed_loop(five(port5), 4.0, min_steps)
+    rt, pt = max(re_ / rs - copy_s, 1e-9), max(pe / ps - copy_s, 1e-9)
+    out["reference_headers"] = {
+        "value": n / rt, "unit": "gridcell-steps/s of the five wrappers frac_wet, canopy_hydrology, surface_radiation, "
+                                 "canopy_temperature, bareground_fluxes", "cores": rthreads, "kind": "reference",
+        "port_same_five": n / pt,
+        "sample": f"{n} columns x {rs} passes, oracle/_ref/libelmref.so (the reference's headers, g++ -O2 -fopenmp, "
+                  f"omp parallel for schedule(static) over columns), {re_:.1f} s",
+    }
+    return out
 
 
-# HIP kernels behind each wrapper (names as rocprofv3 reports them)
-SUB_KERNELS = {
-    "frac_wet": ["elmk::k_frac_wet"],
-    "albedo_snicar": ["elmk::k_alb_main"] + [f"elmk::k_alb_snow<{i}>" for i in range(6)],
-    "canopy_hydrology": ["elmk::k_canopy_hydrology"],
-    "surface_radiation": ["elmk::k_surface_radiation"],
-    "canopy_temperature": ["elmk::k_canopy_temperature"],
-    "bareground_fluxes": ["elmk::k_bg_main", "elmk::k_bg_flux"],
-    "canopy_fluxes": ["elmk::k_cf_count", "elmk::k_cf_init", "elmk::k_cf_iterate", "elmk::k_cf_finish"],
+# HIP kernels behind each wrapper / launch group: name prefixes as rocprofv3 reports them
+KERNEL_PREFIX = {
+    "frac_wet": ("elmk::k_frac_wet",),
+    "albedo_snicar": ("elmk::k_alb_",),
+    "canopy_hydrology": ("elmk::k_canopy_hydrology",),
+    "surface_radiation": ("elmk::k_surface_radiation",),
+    "canopy_temperature": ("elmk::k_canopy_temperature",),
+    "bareground_fluxes": ("elmk::k_bg_",),
+    "canopy_fluxes": ("elmk::k_cf_",),
+    "soil_temperature": ("elmk::k_st_", "elmk::k_soil_temperature"),
+    "fused_stream": ("elmk::k_fz_",),
+    "canopy_iterate": ("elmk::k_cf_iterate", "elmk::k_cf_finish"),
 }
+PROFILE_TAG = "r02"
 
 
-def pmc_traffic(wrapper, args):
-    """HBM bytes per launch of the wrapper's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    calibrated on gfx950, WRITE_SIZE as is; profiles/r01_hbm_traffic_pmc_tier{A,B}.json).  The counters cannot be read
-    from inside this process, so the number is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_pmc_tier{args.tier}.json")
-    if args.cols != 1_000_000 or not os.path.exists(path):
+def kernel_source_hash():
+    """Hash of the kernel sources: the committed PMC tables carry the hash of the build they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "elmkernels_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) and name != "elmk_math_tables.h":
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(group, tier, cols, table=None):
+    """HBM bytes per launch of the group's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    calibrated on gfx950, WRITE_SIZE as is; profiles/<round>_hbm_traffic_pmc_tier{A,B}.json).  The counters cannot be
+    read from inside this process, so the number is only reported for the configuration and the build (source hash) it
+    was measured on; otherwise None, with the reason on stderr."""
+    path = os.path.join(ROOT, "profiles", table or f"{PROFILE_TAG}_hbm_traffic_pmc_tier{tier}.json")
+    if cols != 1_000_000 or not os.path.exists(path) or group not in KERNEL_PREFIX:
         return None
-    k = json.load(open(path))["kernels"]
-    try:
-        return float(sum(k[name]["hbm_bytes_per_launch"] for name in SUB_KERNELS[wrapper]))
-    except KeyError:
+    doc = json.load(open(path))
+    if doc.get("source_hash") not in (None, kernel_source_hash()):
+        print(f"bench.py: {os.path.basename(path)} was measured on another build of the kernels: roofline.traffic = null",
+              file=sys.stderr)
         return None
+    k = doc["kernels"]
+    names = [n for n in k if n.startswith(KERNEL_PREFIX[group])]
+    if not names:
+        print(f"bench.py: no kernel of {group} in {os.path.basename(path)}: roofline.traffic = null", file=sys.stderr)
+        return None
+    return float(sum(k[n]["hbm_bytes_per_launch"] for n in names))
 
 
 SOIL_ALGO_BYTES = 2860  # soil_temperature: 1972 B read + 888 B written per column (tally in DESIGN.md section 9)
 SOIL_RESTORE = ["t_soisno", "h2osoi_ice", "h2osoi_liq", "t_h2osfc", "h2osfc", "h2osno", "snow_depth", "int_snow", "t_grnd"]
 
 
-def timed_steps(D, workload, steps, warmup, sync_all, dist, torch, red_device="cuda"):
-    """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks -> seconds."""
+def make_step(D, workload, fused=False):
+    if hasattr(D, "rehearsal_step"):  # tests only: the device step is the one thing replaced
+        return D.rehearsal_step
     from elmkernels_amd import state as st
 
     if workload == "timestep7":
+        adv = st.timestep7_fused if fused else st.timestep7
+
         def step():
             D.restore_fields()
-            st.timestep7(D, 1800.0)
+            adv(D, 1800.0)
     else:
         def step():
             D.restore_fields()
             st.kokkos_soil_temperature(D, 1800.0)
+    return step
+
+
+def timed_steps(D, workload, steps, warmup, sync_all, dist, torch, red_device="cuda", fused=False):
+    """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks -> seconds."""
+    step = make_step(D, workload, fused)
     for _ in range(warmup):
         step()
     sync_all()
@@ -151,7 +255,8 @@ def timed_steps(D, workload, steps, warmup, sync_all, dist, torch, red_device="c
     for _ in range(steps):
         step()
     D.sync()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -170,47 +275,91 @@ def event_time_soil(D, nsteps):
     return D.profile_wrapper(st.WRAPPER_NAMES.index("soil_temperature"), 1800.0, nsteps)
 
 
-def main():
+def active_bytes(veg_frac, sun_frac):
+    """Per-wrapper algorithmic bytes charging a predicate-gated wrapper only for the columns it works on."""
+    act = dict(ALGO_BYTES)
+    a = GATED_IDLE_BYTES
+    act["albedo_snicar"] = a["albedo_snicar"] + sun_frac * (ALGO_BYTES["albedo_snicar"] - a["albedo_snicar"])
+    act["bareground_fluxes"] = a["bareground_fluxes"] + (1 - veg_frac) * (ALGO_BYTES["bareground_fluxes"] - a["bareground_fluxes"])
+    act["canopy_fluxes"] = a["canopy_fluxes"] + veg_frac * (ALGO_BYTES["canopy_fluxes"] - a["canopy_fluxes"])
+    return act
+
+
+def spawn_ranks(ngpus, argv):
+    """`python bench.py --gpus N` with no launcher: start N rank processes (one per GPU), relay rank 0's JSON line.
+    The parent initialises nothing on the GPU (torch is not even imported here) and never re-executes itself."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cols", type=int, default=1_000_000, help="columns per GPU (BASELINE config 2: 1M)")
+    ap.add_argument("--cols", type=int, default=1_000_000,
+                    help="columns per GPU (BASELINE config 2: 1M; config 4 is --gpus 8 --cols 10000000)")
     ap.add_argument("--tier", default="A", choices=["A", "B"],
                     help="synthetic state (SURVEY.md 8(d)): A fixture-tiled (default), B branch-mix (snow layers, bare ground, C4 ...)")
     ap.add_argument("--workload", default="timestep7", choices=["timestep7", "soil_temperature"],
                     help="timestep7: BASELINE config 2 (the 7 wrappers); soil_temperature: config 3 (the soil-column vertical solve)")
+    ap.add_argument("--fused", action="store_true",
+                    help="the step through elmk_timestep7_fused (BASELINE config 5's launch structure, fp64 state): "
+                         "roofline against the 3 405 B/column-step fused bound")
     ap.add_argument("--no-other-tier", action="store_true", help="skip the secondary measurement on the other tier")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 10 M-column measurement (north_star_10M)")
     ap.add_argument("--seed", type=int, default=0x5EEDE1A0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the seven wrappers as one captured HIP graph (elmk_set_graph): removes host launch latency, "
                          "which dominates below ~100k columns")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the per-kernel HIP-event profile")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world  # under a launcher the launcher decides
 
     import torch
 
+    rehearsal = None
+    if os.environ.get(REHEARSAL_ENV):
+        import importlib
+
+        mod, fn = os.environ[REHEARSAL_ENV].split(":")
+        rehearsal = getattr(importlib.import_module(mod), fn)
+
     dist = None
     ndev = torch.cuda.device_count()
-    if ndev <= 0:
+    if ndev <= 0 and rehearsal is None:
         sys.exit("bench.py needs a HIP device (there is no CPU path)")
     # one process per GPU; a rehearsal with more ranks than GPUs (several ranks share a card) cannot use RCCL and
     # falls back to gloo for the barrier / max-reduce, which is all this benchmark communicates
     shared = world > ndev
-    device_index = local_rank % ndev
+    device_index = local_rank % ndev if ndev > 0 else 0
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
-        torch.cuda.set_device(device_index)
+        if ndev > 0:
+            torch.cuda.set_device(device_index)
         if shared:
             dist.init_process_group("gloo")
         else:
@@ -218,66 +367,94 @@ def main():
     red_device = "cpu" if shared else "cuda"
 
     from elmkernels_amd import decomp
-    from elmkernels_amd import state as st
+
+    st = None
+    if rehearsal is None:
+        from elmkernels_amd import state as st
 
     # weak scaling: every rank owns args.cols columns; the global problem is the 1-D block split of world*cols
     ncols_global = args.cols * world
     start, ncols = decomp.block_range(ncols_global, world, rank)
     soil = args.workload == "soil_temperature"
+    make = rehearsal or build_state
 
-    def prepared(tier):
-        D, host_state = build_state(ncols, device_index, tier, args.seed + rank)
-        if soil:  # the solve follows the seven wrappers: run them once, then keep the state the solve starts from
+    def prepared(tier, n=None):
+        D, host_state = make(ncols if n is None else n, device_index, tier, args.seed + rank)
+        if soil and rehearsal is None:  # the solve follows the seven wrappers: run them once, then keep the state the solve starts from
             st.timestep7(D, 1800.0)
             D.snapshot_fields(SOIL_RESTORE)
             D.sync()
         return D, host_state
 
+    def measure(D, steps, warmup, with_dist):
+        """-> (seconds of the timed region, per-launch-group ms, ms of the whole step by HIP events)."""
+        def sync_all():
+            D.sync()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            if with_dist and dist is not None:
+                dist.barrier()
+
+        el = timed_steps(D, args.workload, steps, warmup, sync_all, dist if with_dist else None, torch, red_device, args.fused)
+        if rehearsal is not None:
+            return el, [], 0.0
+        if soil:
+            return el, [], event_time_soil(D, max(1, args.profile_steps))
+        D.restore_fields()
+        ms, tot = (D.profile_timestep7_fused if args.fused else D.profile_timestep7)(1800.0, max(1, args.profile_steps))
+        return el, ms, tot
+
     D, host_state = prepared(args.tier)
     # population of the predicate-gated wrappers (SURVEY 8(d): "active-bytes" variant of the roofline numerator)
     veg_frac = float((D["frac_veg_nosno"] != 0).mean())
     sun_frac = float((D["coszen"] > 0).mean())
-    if args.graph and not soil:
+    if args.graph and not soil and rehearsal is None:
         D.set_graph(True)
-
-    def sync_all():
-        D.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    elapsed = timed_steps(D, args.workload, args.steps, args.warmup, sync_all, dist, torch, red_device)
-
-    # per-kernel device time, HIP events recorded on the stream the kernels are launched on
-    if soil:
-        ms, ms_total = [], event_time_soil(D, max(1, args.profile_steps))
-    else:
-        D.restore_fields()
-        ms, ms_total = D.profile_timestep7(1800.0, max(1, args.profile_steps))
+    elapsed, ms, ms_total = measure(D, args.steps, args.warmup, True)
     flags, first_bad = D.error_summary()
     state_gb = round(D.device_bytes / 1e9, 3)
+    names = [] if rehearsal is not None else (st.KERNEL_NAMES_FUSED if args.fused else st.KERNEL_NAMES)
 
     other = None
-    if rank == 0 and world == 1 and not args.no_other_tier:
+    north = None
+    solo = rank == 0 and world == 1 and rehearsal is None
+    if solo and not args.no_other_tier:
         D.close()
         D = None
         ot = "B" if args.tier == "A" else "A"
         D2, _ = prepared(ot)
         if args.graph and not soil:
             D2.set_graph(True)
-
-        def sync2():
-            D2.sync()
-            torch.cuda.synchronize()
-
-        el2 = timed_steps(D2, args.workload, args.steps, args.warmup, sync2, None, torch)
-        other = {"tier": {"A": "fixture-tiled", "B": "branch-mix"}[ot], "value": ncols_global * args.steps / el2,
-                 "ms_per_step": el2 / args.steps * 1e3}
+        el2, _, tot2 = measure(D2, args.steps, args.warmup, False)
+        other = {"tier": TIER_NAMES[ot], "value": ncols_global * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
+                 "ms_per_step_events": tot2}
         D2.close()
+    if solo and not args.no_north_star and not soil and args.cols < NORTH_STAR_COLS:
+        # the north-star size in the same run: 10 M columns (64 GB of state + scratch), 5 timed steps per tier
+        if D is not None:
+            D.close()
+            D = None
+        north = {"columns": NORTH_STAR_COLS, "steps": 5, "warmup": 2}
+        byts = ALGO_BYTES_FUSED if args.fused else ALGO_BYTES_STEP
+        for tier in ("A", "B"):
+            Dn, _ = prepared(tier, NORTH_STAR_COLS)
+            vf = float((Dn["frac_veg_nosno"] != 0).mean())
+            sf = float((Dn["coszen"] > 0).mean())
+            eln, msn, totn = measure(Dn, 5, 2, False)
+            act = sum(active_bytes(vf, sf).values())
+            north[TIER_NAMES[tier]] = {
+                "value": NORTH_STAR_COLS * 5 / eln, "ms_per_step": eln / 5 * 1e3, "ms_per_step_events": totn,
+                "timestep_roofline": {
+                    "bytes_per_column_step": byts, "frac": byts * NORTH_STAR_COLS / (totn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_active_bytes": None if args.fused else act * NORTH_STAR_COLS / (totn * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "kernels_ms": {n: round(m, 4) for n, m in zip(names, msn)},
+                "device_state_GB": round(Dn.device_bytes / 1e9, 3),
+            }
+            Dn.close()
 
     if rank == 0:
         value = ncols_global * args.steps / elapsed
-        tier_name = {"A": "fixture-tiled", "B": "branch-mix"}[args.tier]
+        tier_name = TIER_NAMES[args.tier]
         out = {
             "metric": "gridcell-timesteps/sec",
             "value": value,
@@ -292,43 +469,60 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
         }
-        if soil:
+        par = f"columns block-split over {world} rank(s) on {min(world, max(ndev, 1))} GPU(s), no collective"
+        if rehearsal is not None:
+            out["config"] = {"workload": "CPU rehearsal of the multi-rank control flow (tests only)", "columns_per_gpu": args.cols,
+                             "columns_total": ncols_global, "parallelism": par}
+        elif soil:
             gbs = SOIL_ALGO_BYTES * ncols / (ms_total * 1e-3) / 1e9
             out["config"] = {
                 "workload": f"soil-column vertical solve (kokkos_soil_temperature: 21-row pentadiagonal system, phase change), {args.cols} columns per GPU, fp64",
-                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name,
-                "parallelism": f"columns block-split over {world} rank(s) on {min(world, ndev)} GPU(s), no collective",
+                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name, "parallelism": par,
             }
-            out["roofline"] = {"bound": "hbm", "kernel": "k_st_props + k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_st_* + k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic("soil_temperature", args.tier, args.cols, f"{PROFILE_TAG}_hbm_traffic_pmc_soil_tier{args.tier}.json"),
                                "bytes_per_column": SOIL_ALGO_BYTES, "avg_launch_ms": ms_total}
         else:
+            act = active_bytes(veg_frac, sun_frac)
             kern = {}
-            for name, m in zip(st.KERNEL_NAMES, ms):
-                gbs = ALGO_BYTES[name] * ncols / (m * 1e-3) / 1e9 if m > 0 else 0.0
-                kern[name] = {"ms": round(m, 4), "algo_GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
-            dom = max(zip(st.KERNEL_NAMES, ms), key=lambda x: x[1])
-            dom_gbs = ALGO_BYTES[dom[0]] * ncols / (dom[1] * 1e-3) / 1e9
-            step_gbs = ALGO_BYTES_STEP * ncols / (ms_total * 1e-3) / 1e9
+            for name, m in zip(names, ms):
+                kern[name] = {"ms": round(m, 4)}
+                if name in ALGO_BYTES:
+                    # charged only for the columns the wrapper works on (a gated wrapper with nothing to do would
+                    # otherwise show more than the peak)
+                    gbs = act[name] * ncols / (m * 1e-3) / 1e9 if m > 0 else 0.0
+                    kern[name].update({"active_bytes_per_column": round(act[name], 1), "algo_GBps": round(gbs, 1),
+                                       "frac_of_peak": round(min(gbs / HBM_PEAK_GBS, 1.0), 4)})
+            dom = max(zip(names, ms), key=lambda x: x[1])
+            if args.fused:
+                step_bytes = ALGO_BYTES_FUSED
+                # the fused step's launch groups: frac_wet + albedo (960 + 44 B), the streaming stage (what is left of the
+                # 3 405 B bound), the bare-ground list and the leaf-temperature iteration + finish (charged to the stream)
+                dom_bytes = {"albedo_snicar": ALGO_BYTES["albedo_snicar"], "fused_stream": ALGO_BYTES_FUSED - ALGO_BYTES["albedo_snicar"],
+                             "canopy_iterate": ALGO_BYTES["canopy_fluxes"]}.get(dom[0], ALGO_BYTES.get(dom[0], 0))
+            else:
+                step_bytes = ALGO_BYTES_STEP
+                dom_bytes = ALGO_BYTES[dom[0]]
+            dom_gbs = dom_bytes * ncols / (dom[1] * 1e-3) / 1e9
+            step_gbs = step_bytes * ncols / (ms_total * 1e-3) / 1e9
             out["config"] = {
-                "workload": f"full water+energy timestep (7 kernels), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
-                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name,
-                "parallelism": f"columns block-split over {world} rank(s) on {min(world, ndev)} GPU(s), no collective",
+                "workload": f"full water+energy timestep (7 kernels{', fused streaming stage' if args.fused else ''}), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
+                "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name, "parallelism": par,
             }
             out["roofline"] = {
-                "bound": "hbm",
-                "kernel": " + ".join(n.replace("elmk::", "") for n in SUB_KERNELS[dom[0]]),
+                "bound": "hbm", "kernel": f"{dom[0]} ({', '.join(p.replace('elmk::', '') + '*' for p in KERNEL_PREFIX.get(dom[0], ()))})",
                 "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom[0], args), "bytes_per_column": ALGO_BYTES[dom[0]], "avg_launch_ms": dom[1],
+                "traffic": pmc_traffic(dom[0], args.tier, args.cols,
+                                       f"{PROFILE_TAG}_hbm_traffic_pmc_fused_tier{args.tier}.json" if args.fused else None),
+                "bytes_per_column": dom_bytes, "avg_launch_ms": dom[1],
             }
             out["timestep_roofline"] = {
-                "bytes_per_column_step": ALGO_BYTES_STEP, "achieved_GBps": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                "bytes_per_column_step": step_bytes, "achieved_GBps": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                 "ms_per_step_events": ms_total,
-                # the same tally charging a gated wrapper only for the columns it works on: albedo beyond init_timestep's
-                # 500 written bytes only where the sun is up, bareground_fluxes beyond its 24 bytes only on bare columns,
-                # canopy_fluxes beyond 32 bytes only on vegetated ones
-                "active_bytes_per_column_step": round(
-                    ALGO_BYTES_STEP - (1 - sun_frac) * (960 - 500) - veg_frac * (368 - 24) - (1 - veg_frac) * (2076 - 32), 1),
+                # the unfused tally charging a gated wrapper only for the columns it works on
+                "active_bytes_per_column_step": round(sum(act.values()), 1),
+                "frac_active_bytes": None if args.fused else sum(act.values()) * ncols / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "sunlit_fraction": round(sun_frac, 4), "vegetated_fraction": round(veg_frac, 4),
             }
             out["kernels"] = kern
@@ -336,15 +530,18 @@ def main():
         out["device_state_GB"] = state_gb
         if other is not None:
             out["other_tier"] = other
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+        if north is not None:
+            out["north_star_10M"] = north
+        if not args.no_cpu_baseline and world == 1 and rehearsal is None:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(host_state, workload=args.workload)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if D is not None:
         D.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -42,6 +42,12 @@ constexpr int MAXLEV_STAGE = 21;  // widest field (zisoi)
 
 }  // namespace
 
+struct GraphSlot {
+  hipGraphExec_t exec = nullptr;
+  double dt = 0.0;
+  hipStream_t stream = nullptr;
+};
+
 struct elmk_ctx {
   int dev = 0;
   hipStream_t own_stream = nullptr;
@@ -67,9 +73,7 @@ struct elmk_ctx {
   // elmk_set_graph: the seven wrappers of elmk_timestep7 captured once as a HIP graph (kernel nodes + the side-stream
   // fork / join of albedo_snicar) and replayed; key = (dt, stream)
   bool use_graph = false;
-  hipGraphExec_t ts7_exec = nullptr;
-  double ts7_dt = 0.0;
-  hipStream_t ts7_stream = nullptr;
+  GraphSlot graph[2];  // [0] elmk_timestep7, [1] elmk_timestep7_fused
   std::string err;
 };
 
@@ -89,6 +93,35 @@ bool hip_fail(elmk_ctx* ctx, hipError_t e, const char* what)
   do {                                                    \
     if (hip_fail(ctx, (call), #call)) return ELMK_E_HIP;  \
   } while (0)
+
+// Owners for the temporaries of the diagnostic entry points: released on every return path
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  hipError_t create(size_t n)
+  {
+    ev.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+      hipEvent_t e = nullptr;
+      const hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      ev.push_back(e);
+    }
+    return hipSuccess;
+  }
+  hipEvent_t& operator[](size_t i) { return ev[i]; }
+  ~EventList()
+  {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+struct DevBuf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  ~DevBuf()
+  {
+    if (p) (void)hipFree(p);
+  }
+};
 
 int invalid(elmk_ctx* ctx, const char* msg)
 {
@@ -257,7 +290,8 @@ int elmk_destroy(elmk_ctx* ctx)
   if (ctx->snicar) (void)hipFree(ctx->snicar);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d) (void)hipFree(ctx->d);
-  if (ctx->ts7_exec) (void)hipGraphExecDestroy(ctx->ts7_exec);
+  for (GraphSlot& g : ctx->graph)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (ctx->red_or) (void)hipFree(ctx->red_or);
   if (ctx->staging) (void)hipFree(ctx->staging);
   for (char* b : ctx->snap_bufs) (void)hipFree(b);
@@ -288,10 +322,12 @@ int elmk_set_graph(elmk_ctx* ctx, int on)
 {
   if (int rc = enter(ctx)) return rc;
   ctx->use_graph = on != 0;
-  if (!ctx->use_graph && ctx->ts7_exec) {
+  if (!ctx->use_graph) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    (void)hipGraphExecDestroy(ctx->ts7_exec);
-    ctx->ts7_exec = nullptr;
+    for (GraphSlot& g : ctx->graph) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
   }
   return ELMK_OK;
 }
@@ -424,16 +460,34 @@ int elmk_snapshot_fields(elmk_ctx* ctx, const int* fields, int nfields)
   for (char* b : ctx->snap_bufs) (void)hipFree(b);
   ctx->snap_bufs.clear();
   ctx->snap_fields.clear();
+  // a field enters the snapshot only once its buffer exists and its copy has been enqueued; any failure drops the whole
+  // snapshot, so that a later elmk_restore_fields never restores from a partly filled set
+  auto drop = [&]() {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (char* b : ctx->snap_bufs) (void)hipFree(b);
+    ctx->snap_bufs.clear();
+    ctx->snap_fields.clear();
+  };
   for (int i = 0; i < nfields; i++) {
     const int f = fields[i];
     const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype);
     char* b = nullptr;
-    HIPCHK(hipMalloc((void**)&b, bytes));
+    if (hip_fail(ctx, hipMalloc((void**)&b, bytes), "hipMalloc(snapshot)")) {
+      drop();
+      return ELMK_E_NOMEM;
+    }
+    if (hip_fail(ctx, hipMemcpyAsync(b, ctx->fptr[f], bytes, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync(snapshot)")) {
+      (void)hipFree(b);
+      drop();
+      return ELMK_E_HIP;
+    }
     ctx->snap_bufs.push_back(b);
     ctx->snap_fields.push_back(f);
-    HIPCHK(hipMemcpyAsync(b, ctx->fptr[f], bytes, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (hip_fail(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize(snapshot)")) {
+    drop();
+    return ELMK_E_HIP;
+  }
   return ELMK_OK;
 }
 
@@ -645,56 +699,110 @@ int elmk_evaluate_conservation(elmk_ctx* ctx, double dt, double* min_max_sum, do
   return ELMK_OK;
 }
 
-// ELMInterface::advance order (elm_kokkos_interface.cc:289-307)
+// ELMInterface::advance order (elm_kokkos_interface.cc:289-307).  ONE stage table per launch structure drives the plain
+// path, the graph capture and the profiled path, so the three cannot drift apart.
 namespace {
-void enqueue_timestep7(elmk_ctx* ctx, double dt)
+constexpr int TS7_NSTAGE = 7;
+void launch_stage7(elmk_ctx* ctx, int k, double dt)
 {
-  launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
-  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
-  launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
-  launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
-  launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
-  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
-  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  switch (k) {
+    case 0: launch_frac_wet(ctx->d, ctx->ncols, ctx->stream); break;
+    case 1: launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side); break;
+    case 2: launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream); break;
+    case 3: launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream); break;
+    case 4: launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream); break;
+    case 5: launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream); break;
+    default: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
+  }
+}
+typedef void (*stage_fn)(elmk_ctx*, int, double);
+
+// all stages in order; marks (may be null): nstage + 1 events recorded around the stages on the context's stream
+int enqueue_stages(elmk_ctx* ctx, stage_fn fn, int nstage, double dt, hipEvent_t* marks)
+{
+  for (int k = 0; k < nstage; k++) {
+    if (marks) HIPCHK(hipEventRecord(marks[k], ctx->stream));
+    fn(ctx, k, dt);
+  }
+  if (marks) HIPCHK(hipEventRecord(marks[nstage], ctx->stream));
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+// the stages captured once as a HIP graph (kernel nodes + the side-stream fork / join inside albedo_snicar) and replayed
+int run_graph(elmk_ctx* ctx, GraphSlot& g, stage_fn fn, int nstage, double dt)
+{
+  if (!g.exec || g.dt != dt || g.stream != ctx->stream) {
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < nstage; k++) fn(ctx, k, dt);
+    // a launch that failed during capture leaves its error in the runtime and may have invalidated the capture: read it,
+    // and ALWAYS end the capture so that neither the stream nor the forked side streams stay in capture mode
+    const hipError_t launch_err = hipGetLastError();
+    const hipError_t end_err = hipStreamEndCapture(ctx->stream, &graph);
+    if (launch_err != hipSuccess || end_err != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      hip_fail(ctx, launch_err != hipSuccess ? launch_err : end_err,
+               launch_err != hipSuccess ? "kernel launch during graph capture" : "hipStreamEndCapture");
+      return ELMK_E_HIP;
+    }
+    const hipError_t e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (hip_fail(ctx, e, "hipGraphInstantiate")) {
+      g.exec = nullptr;
+      return ELMK_E_HIP;
+    }
+    g.dt = dt;
+    g.stream = ctx->stream;
+  }
+  HIPCHK(hipGraphLaunch(g.exec, ctx->stream));
+  return ELMK_OK;
+}
+
+// nsteps profiled steps: HIP events between the stages on the context's stream; the snapshot (if any) is restored before
+// every step outside the event brackets, so each profiled step does the same work as the caller's timed loop
+int profile_stages(elmk_ctx* ctx, stage_fn fn, int nstage, double dt, int nsteps, float* ms_per_stage, float* ms_total)
+{
+  EventList ev;
+  HIPCHK(ev.create((size_t)nsteps * (nstage + 1)));
+  for (int s = 0; s < nsteps; s++) {
+    if (!ctx->snap_fields.empty())
+      if (int rc = elmk_restore_fields(ctx)) return rc;
+    if (int rc = enqueue_stages(ctx, fn, nstage, dt, &ev[(size_t)s * (nstage + 1)])) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<double> acc((size_t)nstage, 0.0);
+  double tot = 0.0;
+  for (int s = 0; s < nsteps; s++) {
+    hipEvent_t* e = &ev[(size_t)s * (nstage + 1)];
+    for (int k = 0; k < nstage; k++) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e[k], e[k + 1]));
+      acc[k] += ms;
+    }
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e[0], e[nstage]));
+    tot += ms;
+  }
+  if (ms_per_stage)
+    for (int k = 0; k < nstage; k++) ms_per_stage[k] = (float)(acc[k] / nsteps);
+  if (ms_total) *ms_total = (float)(tot / nsteps);
+  return ELMK_OK;
 }
 }  // namespace
 
 int elmk_timestep7(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
-  if (ctx->use_graph) {
-    // ~22 dependent launches cost ~0.5 ms of launch latency however few columns there are; replaying them as one graph
-    // removes the host side of that.  Kernel arguments are the device parameter block (fixed address) and dt.
-    if (!ctx->ts7_exec || ctx->ts7_dt != dt || ctx->ts7_stream != ctx->stream) {
-      if (ctx->ts7_exec) {
-        (void)hipGraphExecDestroy(ctx->ts7_exec);
-        ctx->ts7_exec = nullptr;
-      }
-      hipGraph_t g = nullptr;
-      HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      enqueue_timestep7(ctx, dt);
-      if (hip_fail(ctx, hipStreamEndCapture(ctx->stream, &g), "hipStreamEndCapture")) return ELMK_E_HIP;
-      const hipError_t e = hipGraphInstantiate(&ctx->ts7_exec, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (hip_fail(ctx, e, "hipGraphInstantiate")) {
-        ctx->ts7_exec = nullptr;
-        return ELMK_E_HIP;
-      }
-      ctx->ts7_dt = dt;
-      ctx->ts7_stream = ctx->stream;
-    }
-    HIPCHK(hipGraphLaunch(ctx->ts7_exec, ctx->stream));
-    return ELMK_OK;
-  }
-  launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
-  launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
-  launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
-  launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
-  launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
-  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
-  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
-  HIPCHK(hipGetLastError());
-  return ELMK_OK;
+  // ~22 dependent launches cost ~0.5 ms of launch latency however few columns there are; replaying them as one graph
+  // removes the host side of that.  Kernel arguments are the device parameter block (fixed address) and dt.
+  if (ctx->use_graph) return run_graph(ctx, ctx->graph[0], launch_stage7, TS7_NSTAGE, dt);
+  return enqueue_stages(ctx, launch_stage7, TS7_NSTAGE, dt, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -725,73 +833,33 @@ int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_k
 {
   PHYSICS_PROLOGUE();
   if (nsteps <= 0) return invalid(ctx, "elmk_profile_timestep7: nsteps <= 0");
-  std::vector<hipEvent_t> ev((size_t)nsteps * 8);
-  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-  for (int s = 0; s < nsteps; s++) {
-    hipEvent_t* e = &ev[(size_t)s * 8];
-    // same step as the caller's timed loop: snapshot fields are put back first (outside the event brackets),
-    // otherwise the canopy converges and later steps would measure a shorter iteration than the real one
-    if (!ctx->snap_fields.empty())
-      if (int rc = elmk_restore_fields(ctx)) return rc;
-    HIPCHK(hipEventRecord(e[0], ctx->stream));
-    launch_frac_wet(ctx->d, ctx->ncols, ctx->stream);
-    HIPCHK(hipEventRecord(e[1], ctx->stream));
-    launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side);
-    HIPCHK(hipEventRecord(e[2], ctx->stream));
-    launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
-    HIPCHK(hipEventRecord(e[3], ctx->stream));
-    launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream);
-    HIPCHK(hipEventRecord(e[4], ctx->stream));
-    launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream);
-    HIPCHK(hipEventRecord(e[5], ctx->stream));
-    launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream);
-    HIPCHK(hipEventRecord(e[6], ctx->stream));
-    launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
-    HIPCHK(hipEventRecord(e[7], ctx->stream));
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0}, tot = 0.0;
-  for (int s = 0; s < nsteps; s++) {
-    hipEvent_t* e = &ev[(size_t)s * 8];
-    for (int k = 0; k < 7; k++) {
-      float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, e[k], e[k + 1]));
-      acc[k] += ms;
-    }
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e[0], e[7]));
-    tot += ms;
-  }
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  if (ms_per_kernel)
-    for (int k = 0; k < 7; k++) ms_per_kernel[k] = (float)(acc[k] / nsteps);
-  if (ms_total) *ms_total = (float)(tot / nsteps);
-  return ELMK_OK;
+  return profile_stages(ctx, launch_stage7, TS7_NSTAGE, dt, nsteps, ms_per_kernel, ms_total);
 }
+
+namespace {
+void launch_one_wrapper(elmk_ctx* ctx, int wrapper, double dt)
+{
+  if (wrapper <= ELMK_WRAPPER_CANOPY_FLUXES)
+    launch_stage7(ctx, wrapper, dt);
+  else if (wrapper == ELMK_WRAPPER_SOIL_TEMPERATURE)
+    launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
+  else
+    launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+}
+}  // namespace
 
 int elmk_profile_wrapper(elmk_ctx* ctx, int wrapper, double dt, int nsteps, float* ms_mean)
 {
   PHYSICS_PROLOGUE();
   if (nsteps <= 0 || !ms_mean) return invalid(ctx, "elmk_profile_wrapper: bad arguments");
   if (wrapper < 0 || wrapper > ELMK_WRAPPER_SURFACE_FLUXES) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
-  std::vector<hipEvent_t> ev((size_t)nsteps * 2);
-  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  EventList ev;
+  HIPCHK(ev.create((size_t)nsteps * 2));
   for (int s = 0; s < nsteps; s++) {
     if (!ctx->snap_fields.empty())
       if (int rc = elmk_restore_fields(ctx)) return rc;
     HIPCHK(hipEventRecord(ev[(size_t)s * 2], ctx->stream));
-    switch (wrapper) {
-      case ELMK_WRAPPER_FRAC_WET: launch_frac_wet(ctx->d, ctx->ncols, ctx->stream); break;
-      case ELMK_WRAPPER_ALBEDO_SNICAR: launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side); break;
-      case ELMK_WRAPPER_CANOPY_HYDROLOGY: launch_canopy_hydrology(ctx->d, ctx->ncols, dt, ctx->stream); break;
-      case ELMK_WRAPPER_SURFACE_RADIATION: launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream); break;
-      case ELMK_WRAPPER_CANOPY_TEMPERATURE: launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream); break;
-      case ELMK_WRAPPER_BAREGROUND_FLUXES: launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream); break;
-      case ELMK_WRAPPER_CANOPY_FLUXES: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
-      case ELMK_WRAPPER_SOIL_TEMPERATURE: launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream); break;
-      default: launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
-    }
+    launch_one_wrapper(ctx, wrapper, dt);
     HIPCHK(hipEventRecord(ev[(size_t)s * 2 + 1], ctx->stream));
   }
   HIPCHK(hipGetLastError());
@@ -802,7 +870,6 @@ int elmk_profile_wrapper(elmk_ctx* ctx, int wrapper, double dt, int nsteps, floa
     HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)s * 2], ev[(size_t)s * 2 + 1]));
     acc += ms;
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   *ms_mean = (float)(acc / nsteps);
   return ELMK_OK;
 }
@@ -838,28 +905,19 @@ int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_
   if (int rc = enter(ctx)) return rc;
   if (bytes < 8 || iters <= 0 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
   const int64_t n = bytes / 8;
-  double *a = nullptr, *b = nullptr;
-  HIPCHK(hipMalloc((void**)&a, (size_t)n * 8));
-  if (hip_fail(ctx, hipMalloc((void**)&b, (size_t)n * 8), "hipMalloc")) {
-    (void)hipFree(a);
-    return ELMK_E_NOMEM;
-  }
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipMemsetAsync(a, 0, (size_t)n * 8, ctx->stream));
-  launch_copy(a, b, n, ctx->stream);  // warm-up
-  HIPCHK(hipEventRecord(e0, ctx->stream));
-  for (int i = 0; i < iters; i++) launch_copy(a, b, n, ctx->stream);
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  DevBuf a, b;
+  if (hip_fail(ctx, a.alloc((size_t)n * 8), "hipMalloc") || hip_fail(ctx, b.alloc((size_t)n * 8), "hipMalloc")) return ELMK_E_NOMEM;
+  EventList ev;
+  HIPCHK(ev.create(2));
+  HIPCHK(hipMemsetAsync(a.p, 0, (size_t)n * 8, ctx->stream));
+  launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream);  // warm-up
+  HIPCHK(hipEventRecord(ev[0], ctx->stream));
+  for (int i = 0; i < iters; i++) launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream);
+  HIPCHK(hipEventRecord(ev[1], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
   *gbytes_per_s = 2.0 * (double)n * 8.0 * iters / ((double)ms * 1e-3) / 1e9;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(a);
-  (void)hipFree(b);
   return ELMK_OK;
 }
 

@@ -18,6 +18,14 @@
 // The same header compiles for the host with gcc (tests/test_math_host.py compares it with the live libm on 10^8
 // arguments, bit for bit) and for the device with hipcc (tests/test_gpu_parity.py::test_device_math_bits).
 // No errno, no floating-point exception flags; results (including inf / nan / subnormal) are identical.
+//
+// Provenance and licence (see NOTICE at the repository root): the ALGORITHMS below are those of the GNU C Library 2.35 -
+//   exp / log / pow: Szabolcs Nagy's routines (glibc e_exp.c, e_log.c, e_pow.c; also Arm optimized-routines, MIT);
+//   atan / cos / acos: IBM Accurate Mathematical Library (glibc s_atan.c, s_sin.c, e_asin.c; LGPL-2.1-or-later);
+//   tanh / expm1 / erf / log10: fdlibm (Copyright (C) 1993 by Sun Microsystems, Inc. - permission to use, copy, modify,
+//   and distribute this software is freely granted, provided that this notice is preserved) -
+// restated here from the published algorithms and the disassembly of the image's libm.so.6; each section names its source.
+// Bit-identity is defined against THAT libm build (glibc 2.35, x86-64, FMA variants).
 #pragma once
 #include <stdint.h>
 

@@ -41,6 +41,9 @@
 
 #include <cstring>
 #include <exception>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using AD1 = ELM::Array<double, 1>;
 using AI1 = ELM::Array<int, 1>;
@@ -63,10 +66,29 @@ static const uint32_t REF_THREW = 1u << 31;
 
 extern "C" {
 
+// The five wrapper loops below run under "#pragma omp parallel for schedule(static)": what
+// Kokkos::parallel_for(RangePolicy<OpenMP>(0, ncols)) does with the same lambdas (src/utils/invoke_kernel.hh:24-27).
+// Columns are independent, so results do not depend on the thread count.
+int elmref_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void elmref_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 // canopy_hydrology_kokkos.cc:98-112
 void elmref_frac_wet(elmo_state* S)
 {
   const ELM::LandType L = land_of(S);
+#pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     ELM::canopy_hydrology::fraction_wet(L, S->frac_veg_nosno[c], S->dewmx, S->elai[c], S->esai[c], S->h2ocan[c],
                                         S->fwet[c], S->fdry[c]);
@@ -77,6 +99,7 @@ void elmref_frac_wet(elmo_state* S)
 void elmref_canopy_hydrology(elmo_state* S, double dt)
 {
   const ELM::LandType L = land_of(S);
+#pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     double qflx_irrig = 0.0;
     double qflx_candrip = 0.0, qflx_through_snow = 0.0, qflx_through_rain = 0.0, fracsnow = 0.0, fracrain = 0.0;
@@ -102,6 +125,7 @@ void elmref_canopy_hydrology(elmo_state* S, double dt)
 void elmref_surface_radiation(elmo_state* S)
 {
   const ELM::LandType L = land_of(S);
+#pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     double trd_[2] = {0.0, 0.0}, tri_[2] = {0.0, 0.0};
     AD1 trd(2, trd_), tri(2, tri_);
@@ -130,6 +154,7 @@ void elmref_canopy_temperature(elmo_state* S)
 {
   const ELM::LandType L = land_of(S);
   AD1 displar(ELMO_MXPFT, S->displar), z0mr(ELMO_MXPFT, S->z0mr);
+#pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     double qred = 0.0, hr = 0.0, soilalpha = 0.0;
     bool veg_active = S->veg_active[c] != 0;
@@ -162,6 +187,7 @@ void elmref_canopy_temperature(elmo_state* S)
 void elmref_bareground_fluxes(elmo_state* S)
 {
   const ELM::LandType L = land_of(S);
+#pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     double zldis = 0.0, displa = 0.0, dth = 0.0, dqh = 0.0, obu = 0.0, ur = 0.0, um = 0.0, temp1 = 0.0, temp2 = 0.0,
            temp12m = 0.0, temp22m = 0.0, ustar = 0.0;

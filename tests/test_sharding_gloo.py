@@ -1,10 +1,12 @@
 """The N > 1 path of bench.py on CPU: world_size-2 gloo, one process per rank.
 
-What the multi-GPU run does besides launching kernels - block-split of the global column range, per-rank state
-generation, barrier + max-over-ranks of the timed region, rank-0 aggregation - is exercised here with the oracle
-standing in for the device (the product itself has no CPU path).  Checks that the shards tile the global
-problem exactly and that per-rank results equal the corresponding slice of a single-process run (columns are
-independent: no halo, no collective on the data path)."""
+test_bench_main_*: bench.py's OWN main() - self-spawn of the rank processes (`python bench.py --gpus 2`), and the
+driver's `python -m torch.distributed.run ... bench.py --gpus 2` - with only the device step replaced (tests/rehearsal.py:
+the oracle on this rank's block).  Checks the JSON line (n_gpus, columns_total, weak scaling), that the shards are the
+reference's 1-D block split (src/utils/utils.cc:27-44) and that they tile the undivided problem exactly.
+
+test_two_rank_block_split: the split arithmetic and the one natural collective (global min / max / sum of the
+conservation diagnostics) under gloo."""
 import os
 import sys
 
@@ -53,6 +55,68 @@ def _worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), start=start, count=count, t_veg=S["t_veg"], cgrnd=S["cgrnd"],
              snl=S["snl"], albd=S["albd"], elapsed=float(el.item()), sizes=sizes.numpy(), gmms=gmms)
     dist.destroy_process_group()
+
+
+def _single_process_reference(n):
+    sys.path.insert(0, ROOT)
+    from elmkernels_amd import synth
+    from tests import helpers as H
+    from tests import rehearsal
+
+    ft = H.field_table_from_oracle()
+    cols, scal, soil = synth.make_state(ft, n, tier="B", seed=rehearsal.N_SEED)
+    S = H.oracle_state(cols, scal, soil)
+    S.timestep7(1800.0)
+    return S
+
+
+def _run_bench(cmd, tmp_path, nglobal):
+    import json
+    import subprocess
+
+    env = dict(os.environ, ELMK_BENCH_REHEARSAL="tests.rehearsal:make_state", ELMK_REHEARSAL_OUT=str(tmp_path),
+               ELMK_REHEARSAL_NGLOBAL=str(nglobal), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def _check_shards(tmp_path, line, per_rank, world, steps, warmup):
+    nglobal = per_rank * world
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["steps"] == steps and line["warmup"] == warmup
+    assert line["config"]["columns_total"] == nglobal and line["config"]["columns_per_gpu"] == per_rank
+    assert line["metric"] == "gridcell-timesteps/sec" and line["value"] > 0
+    assert abs(line["value"] - nglobal * steps / (line["ms_per_step"] * 1e-3 * steps)) < 1e-6 * line["value"]
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    from elmkernels_amd import decomp
+
+    assert [(int(p["start"]), int(p["count"])) for p in parts] == decomp.all_ranges(nglobal, world)
+    assert all(int(p["steps"]) == steps + warmup for p in parts)  # W untimed + exactly K timed steps on every rank
+    S = _single_process_reference(nglobal)
+    for name in ("t_veg", "cgrnd", "snl", "albd"):
+        whole = np.concatenate([p[name] for p in parts])
+        assert np.array_equal(whole, S[name], equal_nan=True), name
+
+
+def test_bench_main_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent starts the two rank processes itself."""
+    line = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--cols", "700", "--steps", "2", "--warmup", "1",
+                       "--tier", "B", "--no-cpu-baseline"], tmp_path, 1400)
+    _check_shards(tmp_path, line, 700, 2, 2, 1)
+
+
+def test_bench_main_under_torch_distributed_run(tmp_path):
+    """The driver's launch line for N > 1."""
+    port = 20000 + (os.getpid() % 20000)
+    line = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                       "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--cols", "333",
+                       "--steps", "2", "--warmup", "1", "--tier", "B"], tmp_path, 666)
+    _check_shards(tmp_path, line, 333, 2, 2, 1)
 
 
 def test_two_rank_block_split(tmp_path):

@@ -9,6 +9,9 @@ the tables (2^(i/128), 1/c and log(c) for the 128 sub-intervals) are data of tha
 this image, so the tables are read out of the libm the oracle itself links (the struct is located by its leading
 constants, its layout checked against the mathematical definition of every entry).  Run once; the header is committed.
 
+The tables are numerical data of glibc 2.35 routines (exp / log / pow: Szabolcs Nagy, also MIT in Arm optimized-routines;
+atan / sincos / asin: IBM Accurate Mathematical Library, LGPL-2.1-or-later): see NOTICE at the repository root.
+
 python3 tools/gen_libm_tables.py [/lib/x86_64-linux-gnu/libm.so.6]
 """
 import math
@@ -120,6 +123,8 @@ with open(OUT, "w") as f:
     f.write("// GENERATED by tools/gen_libm_tables.py - do not edit.  Constant tables (IEEE-754 binary64 bit patterns) of the\n")
     f.write("// exp / log / pow of %s, read from its libm.so.6.\n" % ver)
     f.write("// Layout: the __exp_data / __log_data / __pow_log_data structs of sysdeps/ieee754/dbl-64/math_config.h.\n")
+    f.write("// Numerical data of glibc routines: exp / log / pow tables by Szabolcs Nagy (also MIT in Arm optimized-routines); atan /\n")
+    f.write("// sincos / asin tables of the IBM Accurate Mathematical Library (LGPL-2.1-or-later).  See NOTICE at the repository root.\n")
     f.write("#pragma once\n#include <stdint.h>\n\n")
     f.write("// invln2N, shift, negln2hiN, negln2loN, C2, C3, C4, C5\n")
     f.write(emit("elmk_exp_hdr", exp_hdr))

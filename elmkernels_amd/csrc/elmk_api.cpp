@@ -244,36 +244,36 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.land = Land{1, 0, 2, 0, 0};
   h.dewmx = 0.1;
   h.oldfflag = 1;
-  h.snicar = ctx->snicar;
-  h.wk = (double*)ctx->scratch;
-  h.lists = (int32_t*)(ctx->scratch + wk_bytes);
-  h.counters = (uint32_t*)(ctx->scratch + wk_bytes + list_bytes);
-  h.cf_niter = (int32_t*)(ctx->scratch + wk_bytes + list_bytes + cnt_bytes);
+  h.snicar = (gptr<const double>)ctx->snicar;
+  h.wk = (gptr<double>)ctx->scratch;
+  h.lists = (gptr<int32_t>)(ctx->scratch + wk_bytes);
+  h.counters = (gptr<uint32_t>)(ctx->scratch + wk_bytes + list_bytes);
+  h.cf_niter = (gptr<int32_t>)(ctx->scratch + wk_bytes + list_bytes + cnt_bytes);
   {
     char* q = ctx->scratch + wk_bytes + list_bytes + cnt_bytes + hint_bytes;
-    h.cf_rec = (double*)q;
+    h.cf_rec = (gptr<double>)q;
     q += rec_bytes;
-    h.cf_fin = (double*)q;
+    h.cf_fin = (gptr<double>)q;
     q += fin_bytes;
-    h.cf_irec = (int32_t*)q;
+    h.cf_irec = (gptr<int32_t>)q;
     q += irec_bytes;
-    h.cf_pos = (int32_t*)q;
+    h.cf_pos = (gptr<int32_t>)q;
     q += pos_bytes;
-    h.cf_blk = (uint32_t*)q;
+    h.cf_blk = (gptr<uint32_t>)q;
     q += blk_bytes;
-    h.alb_snow = (double*)q;
+    h.alb_snow = (gptr<double>)q;
     q += snow_bytes;
-    h.st_work = (double*)q;
+    h.st_work = (gptr<double>)q;
     q += stw_bytes;
-    h.cons_diag = (double*)q;
+    h.cons_diag = (gptr<double>)q;
     h.cf_nblk = cf_nblk;
   }
   {
     int f = 0;
-#define ELMK_FIELD(name, T, nlev) h.name = (ctype_of<ELMK_##T>::type*)ctx->fptr[f++];
+#define ELMK_FIELD(name, T, nlev) h.name = (gptr<ctype_of<ELMK_##T>::type>)ctx->fptr[f++];
 #include "elmk_fields.def"
 #undef ELMK_FIELD
-    h.err_flags = (uint32_t*)ctx->fptr[f];
+    h.err_flags = (gptr<uint32_t>)ctx->fptr[f];
   }
   ctx->dirty = true;
   if (hip_fail(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) return fail(ELMK_E_HIP);
@@ -684,7 +684,7 @@ int elmk_evaluate_conservation(elmk_ctx* ctx, double dt, double* min_max_sum, do
 {
   PHYSICS_PROLOGUE();
   if (!min_max_sum) return invalid(ctx, "elmk_evaluate_conservation: min_max_sum is NULL");
-  double* diag = ctx->h.cons_diag;
+  double* diag = ELMK_GENERIC(ctx->h.cons_diag);
   double* part = diag + (size_t)8 * ctx->ld;
   double* out = part + (size_t)8 * ELMK_CONS_NPART * 3;
   launch_conservation(ctx->d, ctx->ncols, ctx->ld, dt, diag, part, out, ctx->stream);
@@ -882,11 +882,11 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
   size_t esz = 0;
   int64_t limit = 0;
   if (kind == ELMK_SCRATCH_CF_TRIPS) {
-    src = ctx->h.cf_niter;
+    src = ELMK_GENERIC(ctx->h.cf_niter);
     esz = 4;
     limit = ctx->ncols;
   } else if (kind == ELMK_SCRATCH_WORK) {
-    src = ctx->h.wk;
+    src = ELMK_GENERIC(ctx->h.wk);
     esz = 8;
     limit = (int64_t)WK_N * ctx->ld;
   } else {

@@ -63,6 +63,17 @@ constexpr int NLEVSNO = ELMK_NLEVSNO;
 constexpr int NLEVGRND = ELMK_NLEVGRND;
 constexpr int NLEVTOT = ELMK_NLEVTOT;
 
+// Device pointers of the parameter block are GLOBAL-address-space pointers.  A plain C++ pointer loaded from a struct in
+// memory is a generic ("flat") pointer to the compiler: every access through it is a flat_load / flat_store, which may
+// target LDS, so it cannot be reordered around LDS accesses, counts against both memory counters and returns out of order
+// (each dependent use waits for ALL outstanding memory operations).  With the address space in the type the same source
+// compiles to global_load / global_store with counted waits.
+#define ELMK_GLOBAL __attribute__((address_space(1)))
+template <typename T> using gptr = ELMK_GLOBAL T*;
+// the atomic builtins of HIP take generic pointers: cast at the call (the operation itself is the same memory atomic)
+template <typename T> __host__ __device__ __forceinline__ T* elmk_generic(ELMK_GLOBAL T* p) { return (T*)p; }
+#define ELMK_GENERIC(p) elmk_generic(p)
+
 template <int T> struct ctype_of;
 template <> struct ctype_of<ELMK_F64> { using type = double; };
 template <> struct ctype_of<ELMK_I32> { using type = int32_t; };
@@ -114,7 +125,7 @@ enum : int {
 
 // canopy_fluxes queue records (k_canopy_fluxes.hip): per queue position, SoA [k][position] with stride ld
 constexpr int CF_NCLS = 12;    // scheduling classes: 6 bins of the previous call's trip count x (day, night)
-constexpr int CF_REC_N = 62;   // doubles a column carries into the iteration kernel
+constexpr int CF_REC_N = 44;   // doubles a column carries into the iteration kernel
 constexpr int CF_IREC_N = 3;   // int32: vtype, nrad, frac_veg_nosno
 constexpr int CF_FIN_N = 24;   // doubles the iteration kernel hands to the finishing kernel
 
@@ -128,7 +139,7 @@ constexpr int CPAD = 32;
 // cls in [0, NCLS) or -1; column c goes to list first_list + cls.  One global atomic per class per workgroup;
 // order inside a list follows (workgroup arrival, wave, lane).  All threads of the workgroup must call it.
 template <int NCLS>
-__device__ __forceinline__ void block_classify_append(int32_t* __restrict__ lists, int64_t ld, uint32_t* __restrict__ counters,
+__device__ __forceinline__ void block_classify_append(gptr<int32_t> lists, int64_t ld, gptr<uint32_t> counters,
                                                       int first_list, int cls, int32_t c)
 {
   __shared__ uint32_t s_cnt[NCLS];
@@ -151,7 +162,7 @@ __device__ __forceinline__ void block_classify_append(int32_t* __restrict__ list
   __syncthreads();
   if (threadIdx.x < NCLS) {
     const uint32_t n = s_cnt[threadIdx.x];
-    s_base[threadIdx.x] = n ? atomicAdd(&counters[(first_list + threadIdx.x) * CPAD], n) : 0u;
+    s_base[threadIdx.x] = n ? atomicAdd(ELMK_GENERIC(&counters[(first_list + threadIdx.x) * CPAD]), n) : 0u;
   }
   __syncthreads();
   if (cls >= 0) lists[(int64_t)(first_list + cls) * ld + s_base[cls] + my_off] = c;
@@ -170,25 +181,25 @@ struct DevState {
   double pft_alb[ELMK_MXPFT][ELMK_ALB_NPARAM];
   double z0mr[ELMK_MXPFT], displar[ELMK_MXPFT];
   double albsat[ELMK_NSOILCOL][2], albdry[ELMK_NSOILCOL][2];
-  const double* snicar;  // SN_TOTAL doubles
+  gptr<const double> snicar;  // SN_TOTAL doubles
   // per-call scratch owned by the context (never part of the state contract):
-  double* wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
-  int32_t* lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
-  uint32_t* counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
-  double* cons_diag;   // 8 x ld: conservation diagnostics per column (k_surface_fluxes.hip)
-  double* st_work;     // 82 x ld: thk, cv of the 20 levels (soil_temperature stage 1), then A, Z of the 21 rows of the forward sweep (k_soil_temperature.hip), [row][column]
-  double* alb_snow;    // 28 x ld: SNICAR products of the sunlit snow-covered columns (k_albedo_snicar.hip), by column
-  int32_t* cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
-  double* cf_rec;      // CF_REC_N x ld: inputs of the queued columns, by queue position
-  double* cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position
-  int32_t* cf_irec;    // CF_IREC_N x ld
-  int32_t* cf_pos;     // queue position of each column (-1: not vegetated)
-  uint32_t* cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
+  gptr<double> wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
+  gptr<int32_t> lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
+  gptr<uint32_t> counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
+  gptr<double> cons_diag;   // 8 x ld: conservation diagnostics per column (k_surface_fluxes.hip)
+  gptr<double> st_work;     // 82 x ld: thk, cv of the 20 levels (soil_temperature stage 1), then A, Z of the 21 rows of the forward sweep (k_soil_temperature.hip), [row][column]
+  gptr<double> alb_snow;    // 28 x ld: SNICAR products of the sunlit snow-covered columns (k_albedo_snicar.hip), by column
+  gptr<int32_t> cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
+  gptr<double> cf_rec;      // CF_REC_N x ld: inputs of the queued columns, by queue position
+  gptr<double> cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position
+  gptr<int32_t> cf_irec;    // CF_IREC_N x ld
+  gptr<int32_t> cf_pos;     // queue position of each column (-1: not vegetated)
+  gptr<uint32_t> cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
   int64_t cf_nblk;     // workgroups of 256 columns
-#define ELMK_FIELD(name, T, nlev) ctype_of<ELMK_##T>::type* name;
+#define ELMK_FIELD(name, T, nlev) gptr<ctype_of<ELMK_##T>::type> name;
 #include "elmk_fields.def"
 #undef ELMK_FIELD
-  uint32_t* err_flags;
+  gptr<uint32_t> err_flags;
 };
 
 // std::min / std::max of the reference (<algorithm>): first argument wins ties and NaNs
@@ -352,15 +363,17 @@ __device__ __forceinline__ FvConst fv_const()
 // on the same operands, so results are bit-identical to the call-by-call form (fv_wind / fv_profile above).
 // SAME_Z0: z0m, z0h and z0q are the same value (canopy); otherwise z0h == z0q is still checked at run time.
 // WITH_2M = false leaves temp12m / temp22m untouched (the caller evaluates the 2 m profile later with fv_profile).
+// friction_profiles_zl takes the three displaced heights zl_x = forc_hgt_x - displa (what the profiles read) and whether
+// hgt_q == hgt_t (the reference's short-cut test of friction_velocity_humidity, :107-113)
 template <bool SAME_Z0, bool WITH_2M = true>
-__device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
-                                                  double obu, double z0m, double z0h, double z0q, const FvConst& K,
-                                                  double& ustar, double& temp1, double& temp2, double& temp12m,
-                                                  double& temp22m)
+__device__ __forceinline__ void friction_profiles_zl(double zl_u, double zl_t, double zl_q, bool same_tq, double um,
+                                                     double obu, double z0m, double z0h, double z0q, const FvConst& K,
+                                                     double& ustar, double& temp1, double& temp2, double& temp12m,
+                                                     double& temp22m)
 {
   const double zetam = 1.574, zetat = 0.465;
-  const double zl_u = hgt_u - displa, ze_u = zl_u / obu;  // wind
-  const double zl_t = hgt_t - displa, ze_t = zl_t / obu;  // temperature
+  const double ze_u = zl_u / obu;  // wind
+  const double ze_t = zl_t / obu;  // temperature
   const double zl_2 = 2.0 + z0h, ze_2 = zl_2 / obu;       // 2 m temperature
   // regimes in the reference's test order: very unstable, unstable, stable (zeta <= 1), else very stable
   const bool u1 = ze_u < -zetam, u2 = !u1 && ze_u < 0.0, u3 = !u1 && !u2 && ze_u <= 1.0;
@@ -438,10 +451,10 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
   ustar = VKC * um / du;
   temp1 = VKC / dt;
   if (WITH_2M) temp12m = VKC / d2;
-  if (hgt_q == hgt_t && z0q == z0h) {  // friction_velocity_humidity :107
+  if (same_tq && z0q == z0h) {  // friction_velocity_humidity :107
     temp2 = temp1;
   } else {
-    temp2 = fv_profile<false>(hgt_q - displa, obu, z0q);
+    temp2 = fv_profile<false>(zl_q, obu, z0q);
   }
   if (WITH_2M) {
     if (z0q == z0h) {  // friction_velocity_humidity2m :153
@@ -450,6 +463,15 @@ __device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, do
       temp22m = fv_profile<false>(2.0 + z0q, obu, z0q);
     }
   }
+}
+template <bool SAME_Z0, bool WITH_2M = true>
+__device__ __forceinline__ void friction_profiles(double hgt_u, double hgt_t, double hgt_q, double displa, double um,
+                                                  double obu, double z0m, double z0h, double z0q, const FvConst& K,
+                                                  double& ustar, double& temp1, double& temp2, double& temp12m,
+                                                  double& temp22m)
+{
+  friction_profiles_zl<SAME_Z0, WITH_2M>(hgt_u - displa, hgt_t - displa, hgt_q - displa, hgt_q == hgt_t, um, obu, z0m, z0h, z0q,
+                                         K, ustar, temp1, temp2, temp12m, temp22m);
 }
 
 }  // namespace elmk

@@ -181,7 +181,8 @@ ELMK_MFN double elmk_exp_general(double x)
 // source's nest of range checks costs a wave that runs alone on its SIMD four exec-mask save / restore sequences per
 // call and keeps the scheduler from overlapping the table read with the argument reduction: 197 -> ~90 ns per call in
 // a dependent chain (tests/tools/ubench/math_issue.hip).
-ELMK_MFN double elmk_exp(double x)
+// main path as a branch-free block: the value for 2^-54 <= |x| < 512, `rare` set for every other argument
+ELMK_MFN double elmk_exp_main(double x, int* rare)
 {
   const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52;
   const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
@@ -196,8 +197,14 @@ ELMK_MFN double elmk_exp(double x)
   const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45);
   const double tmp = elmk_exp_poly(r, tail);
   const double scale = elmk_asf64(sbits);
-  double y = ELMK_FMA(scale, tmp, scale);
-  if (__builtin_expect(abstop - 0x3c9u >= 0x3fu, 0)) y = elmk_exp_general(x);
+  *rare = (abstop - 0x3c9u >= 0x3fu);
+  return ELMK_FMA(scale, tmp, scale);
+}
+ELMK_MFN double elmk_exp(double x)
+{
+  int rare;
+  double y = elmk_exp_main(x, &rare);
+  if (__builtin_expect(rare, 0)) y = elmk_exp_general(x);
   return y;
 }
 
@@ -280,10 +287,11 @@ ELMK_MFN double elmk_log_general(double x)
 // The function the kernels call: same bits; the table path (positive normal x outside [1 - 2^-4, 1 + 0x1.09p-4)) is one
 // straight-line block with a single rarely taken branch behind it for zero / negative / subnormal / inf / nan; the
 // near-1 polynomial stays a branch of its own (evaluating both and selecting was measured: 191 -> 236 ns per call).
-ELMK_MFN double elmk_log(double x)
+// table path as a branch-free block: the value for positive normal x outside [1 - 2^-4, 1 + 0x1.09p-4); `near1` set inside
+// that interval (its own polynomial, elmk_log_near1), `rare` set for zero / negative / subnormal / inf / nan
+ELMK_MFN double elmk_log_main(double x, int* near1, int* rare)
 {
   const uint64_t ix = elmk_asu64(x);
-  if (ix - 0x3fee000000000000ull < 0x3090000000000ull) return elmk_log_general(x);  // near 1: its own polynomial
   const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
   const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb459p-3, A3 = 0x1.999b324f10111p-3,
                A4 = -0x1.55575e506c89fp-3;
@@ -307,8 +315,17 @@ ELMK_MFN double elmk_log(double x)
   double p34 = ELMK_FMA(r, A4, A3);
   lo = ELMK_FMA(r2, A0, lo);
   p34 = ELMK_FMA(p34, r2, p12);
-  double y = ELMK_FMA(r3, p34, lo) + hi;
-  if (__builtin_expect(top - 0x0010u >= 0x7ff0u - 0x0010u, 0)) y = elmk_log_general(x);
+  *near1 = (ix - 0x3fee000000000000ull < 0x3090000000000ull);
+  *rare = (top - 0x0010u >= 0x7ff0u - 0x0010u);
+  return ELMK_FMA(r3, p34, lo) + hi;
+}
+ELMK_MFN double elmk_log(double x)
+{
+  const uint64_t ix = elmk_asu64(x);
+  if (ix - 0x3fee000000000000ull < 0x3090000000000ull) return elmk_log_general(x);  // near 1: its own polynomial
+  int near1, rare;
+  double y = elmk_log_main(x, &near1, &rare);
+  if (__builtin_expect(rare, 0)) y = elmk_log_general(x);
   return y;
 }
 
@@ -436,7 +453,8 @@ ELMK_MFN double elmk_pow_general(double x, double y)
 // The function the kernels call: same bits; for positive normal x, 2^-65 <= |y| < 2^63 and 2^-54 <= |y log x| < 512 -
 // everything the physics does - log_inline and exp_inline run as one straight-line block; any other argument takes the
 // single branch to the general form afterwards.
-ELMK_MFN double elmk_pow(double x, double y)
+// main path as a branch-free block; `rare` set for every argument pair outside it
+ELMK_MFN double elmk_pow_main(double x, double y, int* rare)
 {
   const uint64_t ix = elmk_asu64(x);
   const uint32_t topx = (uint32_t)(ix >> 52);
@@ -493,8 +511,14 @@ ELMK_MFN double elmk_pow(double x, double y)
   const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45);
   const double etmp = elmk_exp_poly(er, tail);
   const double scale = elmk_asf64(sbits);
-  double res = ELMK_FMA(scale, etmp, scale);
-  if (__builtin_expect(rare_arg | (abstop - 0x3c9u >= 0x3fu), 0)) res = elmk_pow_general(x, y);
+  *rare = rare_arg | (abstop - 0x3c9u >= 0x3fu);
+  return ELMK_FMA(scale, etmp, scale);
+}
+ELMK_MFN double elmk_pow(double x, double y)
+{
+  int rare;
+  double res = elmk_pow_main(x, y, &rare);
+  if (__builtin_expect(rare, 0)) res = elmk_pow_general(x, y);
   return res;
 }
 
@@ -591,7 +615,8 @@ ELMK_MFN double elmk_pow1(double x) { return x; }
 // The function the kernels call: same bits; the 1 <= |x| < 16 range - all the physics asks for (stability function of the
 // unstable surface layer, chi = (1 - 16 zeta)^(1/4) with -100 <= zeta < 0) - as one straight-line block, any other argument
 // through the single branch to the general form.
-ELMK_MFN double elmk_atan(double x)
+// main path (1 <= |x| < 16) as a branch-free block; `rare` set for every other argument
+ELMK_MFN double elmk_atan_main(double x, int* rare)
 {
   const double HPI = 0x1.921fb54442d18p+0, HPI1 = 0x1.1a62633145c07p-54;
   const double u = __builtin_fabs(x);
@@ -612,10 +637,105 @@ ELMK_MFN double elmk_atan(double x)
   p = ELMK_FMA(z, p, elmk_asf64(c[2]));
   const double yy = ELMK_FMA(-z, p, HPI1);
   const double t = HPI - elmk_asf64(c[1]);
-  double y = elmk_atan_signed(t + yy, x);
-  if (__builtin_expect(!(u >= 1.0 && u < 16.0), 0)) y = elmk_atan_general(x);
+  *rare = !(u >= 1.0 && u < 16.0);
+  return elmk_atan_signed(t + yy, x);
+}
+ELMK_MFN double elmk_atan(double x)
+{
+  int rare;
+  double y = elmk_atan_main(x, &rare);
+  if (__builtin_expect(rare, 0)) y = elmk_atan_general(x);
   return y;
 }
+
+#if defined(__cplusplus)
+// ---- batched forms -----------------------------------------------------------------------------------------------------
+// N independent arguments evaluated in ONE basic block (main paths of all of them, then a single rarely taken branch for
+// whichever of them needs the general form).  A kernel that runs one wave per SIMD executes a dependent fp64 chain at half
+// the issue rate of the pipe (8 cycles of latency, 4 of issue); N >= 2 chains side by side fill it.  Same functions, same
+// bits as N calls of the scalar forms.
+template <int N>
+ELMK_MFN void elmk_exp_n(double (&v)[N])
+{
+  double y[N];
+  int rare[N], any = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) y[i] = elmk_exp_main(v[i], &rare[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) any |= rare[i];
+  if (__builtin_expect(any, 0)) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (rare[i]) y[i] = elmk_exp_general(v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = y[i];
+}
+template <int N>
+ELMK_MFN void elmk_log_n(double (&v)[N])
+{
+  double y[N];
+  int near1[N], rare[N], any_near = 0, any_rare = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) y[i] = elmk_log_main(v[i], &near1[i], &rare[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    any_near |= near1[i];
+    any_rare |= rare[i];
+  }
+  if (any_near) {  // common for the stability functions of a near-neutral surface layer: all N side by side as well
+    double n1[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) n1[i] = elmk_log_near1(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (near1[i]) y[i] = (v[i] == 1.0) ? 0.0 : n1[i];
+  }
+  if (__builtin_expect(any_rare, 0)) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (rare[i] && !near1[i]) y[i] = elmk_log_general(v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = y[i];
+}
+// v[i] = pow(v[i], e[i])
+template <int N>
+ELMK_MFN void elmk_pow_n(double (&v)[N], const double (&e)[N])
+{
+  double y[N];
+  int rare[N], any = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) y[i] = elmk_pow_main(v[i], e[i], &rare[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) any |= rare[i];
+  if (__builtin_expect(any, 0)) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (rare[i]) y[i] = elmk_pow_general(v[i], e[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = y[i];
+}
+template <int N>
+ELMK_MFN void elmk_atan_n(double (&v)[N])
+{
+  double y[N];
+  int rare[N], any = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) y[i] = elmk_atan_main(v[i], &rare[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) any |= rare[i];
+  if (__builtin_expect(any, 0)) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (rare[i]) y[i] = elmk_atan_general(v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = y[i];
+}
+#endif  // __cplusplus
+
 
 // ---- expm1, tanh: glibc 2.35 sysdeps/ieee754/dbl-64/s_expm1.c, s_tanh.c (fdlibm; these have no FMA build on x86-64:
 // plain multiplies and adds in the source's order) ------------------------------------------------------------------------

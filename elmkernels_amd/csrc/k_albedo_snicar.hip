@@ -54,7 +54,7 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
                                             const double albsoi_b, double& albedo, double (&fl)[6], uint32_t& err)
 {
   constexpr int snl_top = 5 - NL;
-  const double* __restrict__ tab = S->snicar;
+  const gptr<const double> tab = S->snicar;
   const double difgauspt[8] = {0.9894009, 0.9445750, 0.8656312, 0.7554044, 0.6178762, 0.4580168, 0.2816036, 0.0950125};
   const double difgauswt[8] = {0.0271525, 0.0622535, 0.0951585, 0.1246290, 0.1495960, 0.1691565, 0.1826034, 0.1894506};
   const double puny = 1.0e-11;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
   // incident irradiance (:88-98)
   const double flx_slrd = (pass == 0) ? 1.0 / (mu_not * ELM_PI) : 0.0;
   const double flx_slri = (pass == 0) ? 0.0 : 1.0;
-  const double* __restrict__ tsnw = tab + ((pass == 0) ? SN_SNW_DRC : SN_SNW_DFS);
+  const gptr<const double> tsnw = tab + ((pass == 0) ? SN_SNW_DRC : SN_SNW_DFS);
 
   // aerosol species 2..7 of this band (:179-210); species 0/1 (BC) depend on the layer
   double ss_aer[8], asm_aer[8], ext_aer[8];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restric
   elmk_math_lds_init<false>();
   const int64_t ld = S->ld;
   const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
-  const int32_t* __restrict__ list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
+  const gptr<const int32_t> list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
   constexpr int snl_top = NLEVSNO - NL;
   const int lane = threadIdx.x & 63;
   const int slot = lane / 10, task = lane - slot * 10;  // slot 6 (lanes 60..63): no column
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restric
     SnowOut out;
     snicar_combine<NL>(g0, pass, mu_not, rds_top, albedo, fl, out);
     if (valid && bnd == 0) {
-      double* __restrict__ o = S->alb_snow + (int64_t)(pass * 14) * ld + c;
+      const gptr<double> o = S->alb_snow + (int64_t)(pass * 14) * ld + c;
       o[0] = out.alb[0];
       o[ld] = out.alb[1];
 #pragma unroll
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restric
         o[(int64_t)(3 + 2 * i) * ld] = out.fabs_[i][1];
       }
     }
-    if (valid && err) atomicOr(&S->err_flags[c], err);
+    if (valid && err) atomicOr(ELMK_GENERIC(&S->err_flags[c]), err);
   }
 }
 
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
     albsoi[0] = LV(albsoi, 0);
     albsoi[1] = LV(albsoi, 1);
     if (h2osno > SN_MIN_SNW) {
-      const double* __restrict__ o = S->alb_snow + c;
+      const gptr<const double> o = S->alb_snow + c;
       sd.alb[0] = o[0];
       sd.alb[1] = o[ld];
       si.alb[0] = o[(int64_t)14 * ld];

@@ -57,24 +57,61 @@ __device__ __forceinline__ void psn_quadratic(double a, double b, double c, doub
   }
 }
 
-// per-column, iteration-invariant part of photosynthesis() (:22-61, :109-114, :135, :152-154); the PFT constants
-// themselves are read from the parameter table where they are used (L1-resident, keyed by vtype)
-struct PsnInv {
-  bool c3flag;
-  double vcmax25top, jmax25top, tpu25top, kp25top, lmr25top;
-  double vcmaxse, jmaxse, tpuse, vcmaxc, jmaxc, tpuc, lmrc;
-  double cf, kc25, ko25, cp25;
-  double qe, theta_cj, bbbopt, mbbopt;
-  // activation / deactivation energies and entropy terms of the column's PFT, read per trip by psn_temp: kept in
-  // registers, so that a trip issues no global load at all
-  double lmrha, lmrhd, lmrse, vcmaxha, vcmaxhd, jmaxha, jmaxhd, tpuha, tpuhd, kcha, koha, cpha;
+// Iteration-invariant inputs of photosynthesis() (:22-61, :109-114, :135, :152-154), by where they vary:
+//   * per plant functional type (and the day-length factor, one value per call): a row of PFT_N doubles that k_cf_iterate
+//     evaluates once per workgroup into LDS (cf_pft_row).  The activation energies are stored divided by
+//     RGAS * 1e-3 * (TFRZ + 25), the first operation of ft() (:623-625: ha / (...) * (1 - (TFRZ + 25) / tl), evaluated
+//     left to right), so a trip spends no division on them;
+//   * per column: PsnCol, assembled from the queue record when the column is loaded (cf_psn_column).
+enum : int {
+  PFT_lmrha_c, PFT_lmrhd, PFT_lmrse, PFT_vcmaxha_c, PFT_vcmaxhd, PFT_jmaxha_c, PFT_jmaxhd, PFT_tpuha_c, PFT_tpuhd, PFT_kcha_c,
+  PFT_koha_c, PFT_cpha_c, PFT_qe, PFT_theta_cj, PFT_bbbopt, PFT_mbbopt, PFT_c3, PFT_vcmax25top, PFT_lmrc, PFT_sqrt_dleaf,
+  PFT_N,
+  PFT_STRIDE = PFT_N + 1  // odd: rows of different plant types start in different LDS banks
 };
+__device__ __forceinline__ void cf_pft_row(const DevState* __restrict__ S, int v, double* __restrict__ row)
+{
+  const double* __restrict__ P = S->pft_psn[v];
+  const double k25 = RGAS * 1.0e-3 * (TFRZ + 25.0);
+  row[PFT_lmrha_c] = P[P_lmrha] / k25;
+  row[PFT_lmrhd] = P[P_lmrhd];
+  row[PFT_lmrse] = P[P_lmrse];
+  row[PFT_vcmaxha_c] = P[P_vcmaxha] / k25;
+  row[PFT_vcmaxhd] = P[P_vcmaxhd];
+  row[PFT_jmaxha_c] = P[P_jmaxha] / k25;
+  row[PFT_jmaxhd] = P[P_jmaxhd];
+  row[PFT_tpuha_c] = P[P_tpuha] / k25;
+  row[PFT_tpuhd] = P[P_tpuhd];
+  row[PFT_kcha_c] = P[P_kcha] / k25;
+  row[PFT_koha_c] = P[P_koha] / k25;
+  row[PFT_cpha_c] = P[P_cpha] / k25;
+  row[PFT_qe] = P[P_qe];
+  row[PFT_theta_cj] = P[P_theta_cj];
+  row[PFT_bbbopt] = P[P_bbbopt];
+  row[PFT_mbbopt] = P[P_mbbopt];
+  row[PFT_c3] = (round(P[P_c3psn]) == 1) ? 1.0 : 0.0;
+  // vcmax25top (:28-44): leaf nitrogen, the day-length factor and the nitrogen limitation
+  const double dl = S->dayl, mdl = S->max_dayl;
+  const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
+  const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
+  const double act25 = P[P_act25] * 1000.0 / 60.0;
+  double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
+  vcmax25top *= P[P_fnitr];
+  row[PFT_vcmax25top] = vcmax25top;
+  row[PFT_lmrc] = psn_fth25(P[P_lmrhd], P[P_lmrse]);
+  row[PFT_sqrt_dleaf] = sqrt(P[P_dleaf]);
+}
 
 // per-trip temperature factors shared by the sunlit and shaded call
 struct PsnTemp {
   double ft_vcmax, fth_vcmax, ft_jmax, fth_jmax, ft_tpu, fth_tpu, ft_lmr, fth_lmr;
   double p2, e_lmr_c4, e_vc4a, e_vc4b;  // C4 forms (:94-95, :120-124)
   double kc, ko, cp;
+};
+// what one phase of photosynthesis() reads besides PsnTemp
+struct PsnCol {
+  bool c3flag;
+  double vcmax25top, jmax25top, cf, qe, theta_cj, bbbopt, mbbopt;
 };
 
 // the by-reference argument pack of ci_func / brent / hybrid
@@ -236,79 +273,102 @@ __device__ __forceinline__ void psn_hybrid(double x0, CiCtx& k)
   }
 }
 
+// ft / fth with the pre-divided activation energy and the trip's (1 - (TFRZ + 25) / tl) (:623-630)
+__device__ __forceinline__ double psn_ft_c(double ha_c, double fac) { return elmk_exp(ha_c * fac); }
+
 // t_veg-dependent factors of one trip (photosynthesis_impl.hh:63-135); the carboxylation / electron-transport /
-// Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase
-__device__ __forceinline__ PsnTemp psn_temp(const PsnInv& I, const double* __restrict__ P, double t_veg, bool day)
+// Michaelis-Menten factors only feed the daytime branch (par_z > 0) of either phase.  R: the column's PFT row in LDS.
+__device__ __forceinline__ PsnTemp psn_temp(const double* R, bool c3flag, double vcmaxse, double jmaxse, double vcmaxc,
+                                            double jmaxc, double tpuc, double kc25, double ko25, double cp25, double t_veg,
+                                            bool day)
 {
   PsnTemp T;
   T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
   T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
-  if (I.c3flag) {
-    T.ft_lmr = psn_ft(t_veg, I.lmrha);
-    T.fth_lmr = psn_fth(t_veg, I.lmrhd, I.lmrse, I.lmrc);
+  const double fac = (1.0 - (TFRZ + 25.0) / t_veg);
+  if (c3flag) {
+    T.ft_lmr = psn_ft_c(R[PFT_lmrha_c], fac);
+    T.fth_lmr = psn_fth(t_veg, R[PFT_lmrhd], R[PFT_lmrse], R[PFT_lmrc]);
   } else {
     T.p2 = elmk_pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
     T.e_lmr_c4 = elmk_exp(1.3 * (t_veg - (TFRZ + 55.0)));
   }
   if (day) {
-    if (I.c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
-      T.ft_vcmax = psn_ft(t_veg, I.vcmaxha);
-      T.fth_vcmax = psn_fth(t_veg, I.vcmaxhd, I.vcmaxse, I.vcmaxc);
+    if (c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
+      T.ft_vcmax = psn_ft_c(R[PFT_vcmaxha_c], fac);
+      T.fth_vcmax = psn_fth(t_veg, R[PFT_vcmaxhd], vcmaxse, vcmaxc);
     } else {
       T.e_vc4a = elmk_exp(0.2 * ((TFRZ + 15.0) - t_veg));
       T.e_vc4b = elmk_exp(0.3 * (t_veg - (TFRZ + 40.0)));
     }
-    T.ft_jmax = psn_ft(t_veg, I.jmaxha);
-    T.fth_jmax = psn_fth(t_veg, I.jmaxhd, I.jmaxse, I.jmaxc);
-    T.ft_tpu = psn_ft(t_veg, I.tpuha);
-    T.fth_tpu = psn_fth(t_veg, I.tpuhd, I.tpuse, I.tpuc);
-    T.kc = I.kc25 * psn_ft(t_veg, I.kcha);
-    T.ko = I.ko25 * psn_ft(t_veg, I.koha);
-    T.cp = I.cp25 * psn_ft(t_veg, I.cpha);
+    T.ft_jmax = psn_ft_c(R[PFT_jmaxha_c], fac);
+    T.fth_jmax = psn_fth(t_veg, R[PFT_jmaxhd], jmaxse, jmaxc);
+    T.ft_tpu = psn_ft_c(R[PFT_tpuha_c], fac);
+    T.fth_tpu = psn_fth(t_veg, R[PFT_tpuhd], vcmaxse, tpuc);  // tpuse = vcmaxse (:48)
+    T.kc = kc25 * psn_ft_c(R[PFT_kcha_c], fac);
+    T.ko = ko25 * psn_ft_c(R[PFT_koha_c], fac);
+    T.cp = cp25 * psn_ft_c(R[PFT_cpha_c], fac);
   }
   return T;
 }
 
-// photosynthesis() for one phase (sunlit or shaded), nlevcan == 1 (:63-282)
-__device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, int nrad, double forc_pbot, double esat_tv,
-                                            double eair, double oair, double cair, double rb, double btran,
-                                            double vcmaxcint, double par_z, double lai_z, uint32_t& err)
+// photosynthesis() for one phase (sunlit or shaded), nlevcan == 1 (:63-282), in two steps so that the trip's temperature
+// factors (PsnTemp, 15 doubles) are consumed for BOTH phases before the first root find starts and do not sit in registers
+// across it: psn_phase_inputs scales the rates of one phase (:89-127, :203-206), psn_phase_solve is the rest.
+struct PsnPhaseIn {
+  double lmr_z, vcmax_z, jmax_z, tpu_z, kp_z;
+};
+__device__ __forceinline__ PsnPhaseIn psn_phase_inputs(const PsnCol& I, const PsnTemp& T, double btran, double vcmaxcint,
+                                                       double par_z)
+{
+  PsnPhaseIn q;
+  const double nscaler = vcmaxcint;
+  const double lmr25top = I.c3flag ? I.vcmax25top * 0.015 : I.vcmax25top * 0.025;  // (:56-61)
+  const double lmr25 = lmr25top * nscaler;
+  if (I.c3flag) {
+    q.lmr_z = lmr25 * T.ft_lmr * T.fth_lmr;
+  } else {
+    q.lmr_z = lmr25 * T.p2;
+    q.lmr_z /= (1.0 + T.e_lmr_c4);
+  }
+  if (par_z <= 0.0) {
+    q.vcmax_z = 0.0;
+    q.jmax_z = 0.0;
+    q.tpu_z = 0.0;
+    q.kp_z = 0.0;
+  } else {
+    const double vcmax25 = I.vcmax25top * nscaler;
+    const double jmax25 = I.jmax25top * nscaler;
+    const double tpu25 = (0.167 * I.vcmax25top) * nscaler;   // tpu25top (:42)
+    const double kp25 = (20000.0 * I.vcmax25top) * nscaler;  // kp25top (:43)
+    q.vcmax_z = vcmax25 * T.ft_vcmax * T.fth_vcmax;  // overwritten for C4 just below, as in the reference (:115-123)
+    q.jmax_z = jmax25 * T.ft_jmax * T.fth_jmax;
+    q.tpu_z = tpu25 * T.ft_tpu * T.fth_tpu;
+    if (!I.c3flag) {
+      q.vcmax_z = vcmax25 * T.p2;
+      q.vcmax_z /= (1.0 + T.e_vc4a);
+      q.vcmax_z /= (1.0 + T.e_vc4b);
+    }
+    q.kp_z = kp25 * T.p2;
+  }
+  q.vcmax_z *= btran;
+  q.lmr_z *= btran;
+  return q;
+}
+
+// what the solve of a phase reads of the column and the trip (everything else comes through PsnPhaseIn)
+struct PsnSolveIn {
+  bool c3flag;
+  double cf, qe, theta_cj, bbbopt, mbbopt;  // column / plant type
+  double cp, kc, ko;                        // trip (PsnTemp)
+};
+__device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const PsnPhaseIn& q, int nrad, double forc_pbot,
+                                                  double esat_tv, double eair, double oair, double cair, double rb,
+                                                  double btran, double par_z, double lai_z, uint32_t& err)
 {
   if (nrad <= 0) return 0.0;  // laican == 0 -> rs = 0 (:266-281)
   const double fnps = 0.15;
   const double theta_psii = 0.7;
-  const double nscaler = vcmaxcint;
-  const double lmr25 = I.lmr25top * nscaler;
-  double lmr_z, vcmax_z, jmax_z, tpu_z, kp_z;
-  if (I.c3flag) {
-    lmr_z = lmr25 * T.ft_lmr * T.fth_lmr;
-  } else {
-    lmr_z = lmr25 * T.p2;
-    lmr_z /= (1.0 + T.e_lmr_c4);
-  }
-  if (par_z <= 0.0) {
-    vcmax_z = 0.0;
-    jmax_z = 0.0;
-    tpu_z = 0.0;
-    kp_z = 0.0;
-  } else {
-    const double vcmax25 = I.vcmax25top * nscaler;
-    const double jmax25 = I.jmax25top * nscaler;
-    const double tpu25 = I.tpu25top * nscaler;
-    const double kp25 = I.kp25top * nscaler;
-    vcmax_z = vcmax25 * T.ft_vcmax * T.fth_vcmax;  // overwritten for C4 just below, as in the reference (:115-123)
-    jmax_z = jmax25 * T.ft_jmax * T.fth_jmax;
-    tpu_z = tpu25 * T.ft_tpu * T.fth_tpu;
-    if (!I.c3flag) {
-      vcmax_z = vcmax25 * T.p2;
-      vcmax_z /= (1.0 + T.e_vc4a);
-      vcmax_z /= (1.0 + T.e_vc4b);
-    }
-    kp_z = kp25 * T.p2;
-  }
-  vcmax_z *= btran;
-  lmr_z *= btran;
-
   const double gb = 1.0 / rb;
   const double gb_mol = gb * I.cf;
   const double bbb = dmax(I.bbbopt * btran, 1.0);
@@ -321,7 +381,7 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
     const double rh_can = ceair / esat_tv;
     const double qabs = 0.5 * (1.0 - fnps) * par_z * 4.6;
     double r1, r2;
-    psn_quadratic(theta_psii, -(qabs + jmax_z), qabs * jmax_z, r1, r2, err);
+    psn_quadratic(theta_psii, -(qabs + q.jmax_z), qabs * q.jmax_z, r1, r2, err);
     const double je = dmin(r1, r2);
     const double ci0 = I.c3flag ? 0.7 * cair : 0.4 * cair;
     CiCtx k;
@@ -329,17 +389,17 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
     k.je = je;
     k.cair = cair;
     k.oair = oair;
-    k.lmr_z = lmr_z;
+    k.lmr_z = q.lmr_z;
     k.par_z = par_z;
     k.rh_can = rh_can;
-    k.vcmax_z = vcmax_z;
+    k.vcmax_z = q.vcmax_z;
     k.forc_pbot = forc_pbot;
-    k.cp = T.cp;
-    k.kc = T.kc;
-    k.ko = T.ko;
+    k.cp = I.cp;
+    k.kc = I.kc;
+    k.ko = I.ko;
     k.qe = I.qe;
-    k.tpu_z = tpu_z;
-    k.kp_z = kp_z;
+    k.tpu_z = q.tpu_z;
+    k.kp_z = q.kp_z;
     k.theta_cj = I.theta_cj;
     k.bbb = bbb;
     k.mbb = I.mbbopt;
@@ -390,17 +450,19 @@ __device__ __forceinline__ double psn_phase(const PsnInv& I, const PsnTemp& T, i
 #define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
 #endif
 constexpr int CF_REFILL_MIN = 8;
+#ifndef CF_PRIO_TRIPS
+#define CF_PRIO_TRIPS 10  // trips after which a column makes its wave a priority wave (k_cf_iterate)
+#endif
 constexpr int CF_BLOCK_EXTRA = 24;  // queue positions a wave claims beyond what a refill needs (its private block)
 
-// doubles of a queue record (k_cf_init -> k_cf_iterate)
+// doubles of a queue record (k_cf_init -> k_cf_iterate): the column's inputs of the iteration that are not recomputed
+// from other record fields at a few instructions each when the column is loaded (w_lai, cf, cp25, the t10 terms, qsat of
+// the start temperature) or per plant functional type at kernel start (PFT_* below)
 #define CF_REC_FIELDS(X)                                                                                               \
   X(forc_pbot) X(forc_q) X(forc_th) X(forc_rho) X(thm) X(thv) X(elai) X(esai) X(qg) X(t_grnd) X(z0mg) X(z0mv)          \
   X(hgt_u) X(hgt_t) X(hgt_q) X(displa) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha) X(rdl_num) X(soilbeta)        \
-  X(sabv) X(h2ocan) X(air) X(bir) X(cir) X(lw_grnd) X(sqrt_dleaf) X(w_lai) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun)   \
-  X(parsha) X(lai_sun_z) X(lai_sha_z)                                                                                  \
-  X(vcmax25top) X(jmax25top) X(tpu25top) X(kp25top) X(lmr25top) X(vcmaxse) X(jmaxse) X(vcmaxc) X(jmaxc) X(tpuc)        \
-  X(lmrc) X(cf) X(cp25) X(qe) X(theta_cj) X(bbbopt) X(mbbopt)                                                          \
-  X(t_veg) X(btran) X(um) X(obu) X(el) X(qsatl) X(qsatldT)
+  X(sabv) X(h2ocan) X(air) X(bir) X(cir) X(lw_grnd) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun) X(parsha) X(lai_sun_z)   \
+  X(lai_sha_z) X(t10) X(vcmaxc) X(jmaxc) X(tpuc) X(t_veg) X(btran) X(um) X(obu)
 // doubles of a finish record (k_cf_iterate -> k_cf_finish)
 #define CF_FIN_FIELDS(X)                                                                                               \
   X(t_veg) X(btran) X(qflx_tran_veg) X(qflx_evap_veg) X(eflx_sh_veg) X(wtg) X(wtl0) X(wta0) X(wtal) X(wtgq) X(wtalq)   \
@@ -496,7 +558,7 @@ __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S
     const int k = threadIdx.x;
     uint32_t n = 0u;
     for (int t = 0; t < CF_COUNT_TILES; t++) n += s_cnt[t][k];
-    uint32_t base = n ? atomicAdd(&CF_CLASS_COUNT(S, k), n) : 0u;
+    uint32_t base = n ? atomicAdd(ELMK_GENERIC(&CF_CLASS_COUNT(S, k)), n) : 0u;
     for (int t = 0; t < CF_COUNT_TILES; t++) {
       if (tile0 + t < S->cf_nblk) S->cf_blk[(int64_t)k * S->cf_nblk + tile0 + t] = base;
       base += s_cnt[t][k];
@@ -551,6 +613,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   if (inside) S->cf_pos[c] = (int32_t)pos;
 
   if (inside && !veg) {
+    S->cf_niter[c] &= (int32_t)0xFFFF0000;  // trips of this call: 0 (not vegetated); the scheduling hint stays
     if (!L.urbpoi) {
       S->btran[c] = 0.0;
       S->t_veg[c] = S->forc_tbot[c];
@@ -565,7 +628,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 
   // record fields are stored as soon as they are final (PUT), so few of them are live at any time
   CfRec r;
-  double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
+  const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
 #define PUT(n) rec[REC_##n * 8] = r.n;
   const int snl = S->snl[c];
   const int vtype = S->vtype[c];
@@ -697,9 +760,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     r.lai_sha_z = S->laisha_z[c];
   }
   PUT(parsun) PUT(parsha) PUT(lai_sun_z) PUT(lai_sha_z)
-  // loop-invariant sub-expressions of the iteration body (:272, :301-303, :270)
-  r.w_lai = elmk_exp(-(r.elai + r.esai));
-  PUT(w_lai)
+  // loop-invariant sub-expression of the iteration body (:301-303)
   {
     const double snow_depth_c = 0.05;
     const double fsno_dl = S->snow_depth[c] / snow_depth_c;
@@ -707,8 +768,6 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
     r.rdl_num = (1.0 - elmk_exp(-elai_dl));
     PUT(rdl_num)
   }
-  r.sqrt_dleaf = sqrt(P[P_dleaf]);
-  PUT(sqrt_dleaf)
 
   // initial flux profile and Monin-Obukhov length (:158-181)
   {
@@ -730,64 +789,27 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   PUT(lw_grnd)
   S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
 
-  // iteration-invariant part of photosynthesis() (photosynthesis_impl.hh:22-61, :91, :109-114, :135, :152-154)
+  // iteration-invariant part of photosynthesis() that needs an exp per column (photosynthesis_impl.hh:46-55); the rest is
+  // recomputed by k_cf_iterate when it loads the column (cf_psn_column) or once per plant functional type (cf_pft_row)
   {
-    const double dl = S->dayl, mdl = S->max_dayl;
-    const double dayl_factor = dmin(1.0, dmax(0.01, (dl * dl) / (mdl * mdl)));
-    const double t10 = S->t10[c];
-    const bool c3flag = (round(P[P_c3psn]) == 1);
-    const double lnc = 1.0 / (P[P_slatop] * P[P_leafcn]);
-    const double act25 = P[P_act25] * 1000.0 / 60.0;
-    double vcmax25top = lnc * P[P_flnr] * P[P_fnr] * act25 * dayl_factor;
-    vcmax25top *= P[P_fnitr];
-    r.vcmax25top = vcmax25top;
-    PUT(vcmax25top)
-    r.jmax25top = (2.59 - 0.035 * dmin(dmax((t10 - TFRZ), 11.0), 35.0)) * vcmax25top;
-    PUT(jmax25top)
-    r.tpu25top = 0.167 * vcmax25top;
-    PUT(tpu25top)
-    r.kp25top = 20000.0 * vcmax25top;
-    PUT(kp25top)
-    r.lmr25top = c3flag ? vcmax25top * 0.015 : vcmax25top * 0.025;
-    PUT(lmr25top)
-    r.vcmaxse = 668.39 - 1.07 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    PUT(vcmaxse)
-    r.jmaxse = 659.70 - 0.75 * dmin(dmax((t10 - TFRZ), 11.0), 35.0);
-    PUT(jmaxse)
-    r.vcmaxc = psn_fth25(P[P_vcmaxhd], r.vcmaxse);
+    r.t10 = S->t10[c];
+    PUT(t10)
+    const double vcmaxse = 668.39 - 1.07 * dmin(dmax((r.t10 - TFRZ), 11.0), 35.0);
+    const double jmaxse = 659.70 - 0.75 * dmin(dmax((r.t10 - TFRZ), 11.0), 35.0);
+    r.vcmaxc = psn_fth25(P[P_vcmaxhd], vcmaxse);
     PUT(vcmaxc)
-    r.jmaxc = psn_fth25(P[P_jmaxhd], r.jmaxse);
+    r.jmaxc = psn_fth25(P[P_jmaxhd], jmaxse);
     PUT(jmaxc)
-    r.tpuc = psn_fth25(P[P_tpuhd], r.vcmaxse);
+    r.tpuc = psn_fth25(P[P_tpuhd], vcmaxse);
     PUT(tpuc)
-    r.lmrc = psn_fth25(P[P_lmrhd], P[P_lmrse]);
-    PUT(lmrc)
-    r.cf = r.forc_pbot / (RGAS * 1.0e-3 * r.thm) * 1.e06;
-    PUT(cf)
-    const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
-    r.cp25 = 0.5 * derive_forc_po2(r.forc_pbot) / sco;
-    PUT(cp25)
-    r.qe = P[P_qe];
-    PUT(qe)
-    r.theta_cj = P[P_theta_cj];
-    PUT(theta_cj)
-    r.bbbopt = P[P_bbbopt];
-    PUT(bbbopt)
-    r.mbbopt = P[P_mbbopt];
-    PUT(mbbopt)
   }
 
-  // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
+  // iteration start value (canopy_fluxes_impl.hh:154-166 and :203-215)
   r.t_veg = S->t_veg[c];
   PUT(t_veg)
-  {
-    double deldT;
-    qsat(r.t_veg, r.forc_pbot, r.el, deldT, r.qsatl, r.qsatldT);
-    PUT(el) PUT(qsatl) PUT(qsatldT)
-  }
 
 #undef PUT
-  int32_t* __restrict__ irec = S->cf_irec + pos;
+  const gptr<int32_t> irec = S->cf_irec + pos;
   irec[(int64_t)IREC_vtype * ld] = vtype;
   irec[(int64_t)IREC_nrad * ld] = nrad;
   irec[(int64_t)IREC_fvn * ld] = S->frac_veg_nosno[c];
@@ -799,15 +821,60 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
 // position, so a wave never waits for its slowest column (trip counts range from 3 to 41).  Refill is batched
 // (CF_REFILL_MIN idle lanes, or nothing left to do): the lanes of a batch take consecutive positions, so the record
 // loads are coalesced.  Night columns ride in the idle lanes of waves busy with day columns: their trip is a subset.
+//
+// Two waves per SIMD.  A trip is long dependent fp64 chains (Horner forms, Newton steps of divisions and square roots,
+// table look-ups in LDS): one wave alone keeps the fp64 pipe about half busy, a second one fills the gaps.  That needs
+// the kernel inside 256 registers per lane, and a column brings ~45 constants with it - 90 registers that are each read
+// once or twice per trip.  So the column's constants live in LDS (CF_LDS_FIELDS: one 8-byte slot per lane and field,
+// [field][lane]: a wave reads 512 contiguous bytes, conflict-free) and only the few that every section of a trip uses
+// stay in registers (CF_REG_FIELDS); what depends on the plant type alone is one LDS row per type (cf_pft_row).  Moving a
+// field between the two lists changes nothing else: every access goes through C(name).
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
+#define CF_REG_FIELDS(X) X(forc_pbot) X(t_grnd) X(thm) X(forc_q) X(qg) X(elai_esai) X(forc_rho)
+#define CF_LDS_FIELDS(X)                                                                                               \
+  X(forc_th) X(thv) X(elai) X(z0mg) X(z0mv) X(zl_u) X(zl_t) X(zl_q) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha)  \
+  X(rdl_num) X(soilbeta) X(rad_in) X(h2ocan_dt) X(bir) X(lw_term) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun) X(parsha)  \
+  X(lai_sun_z) X(lai_sha_z) X(w_lai) X(tc10) X(vcmaxc) X(jmaxc) X(tpuc) X(cf) X(cp25)
+struct CfRegs {
+#define X(n) double n;
+  CF_REG_FIELDS(X)
+#undef X
+};
+enum : int {
+#define X(n) CL_##n,
+  CF_LDS_FIELDS(X)
+#undef X
+  CF_NLDS
+};
+constexpr int CF_ITER_THREADS = 512;  // 8 waves = two per SIMD; one workgroup per CU shares one copy of the math tables
+typedef double CfLds[CF_ITER_THREADS];
+#define X(n)                                                                                              \
+  __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const CfLds* s, int t) { return R.n; }    \
+  __device__ __forceinline__ void cf_set_##n(CfRegs& R, CfLds* s, int t, double v) { R.n = v; }
+CF_REG_FIELDS(X)
+#undef X
+#define X(n)                                                                                                       \
+  __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const CfLds* s, int t) { return s[CL_##n][t]; }    \
+  __device__ __forceinline__ void cf_set_##n(CfRegs& R, CfLds* s, int t, double v) { s[CL_##n][t] = v; }
+CF_LDS_FIELDS(X)
+#undef X
+#define C(n) cf_get_##n(R, s_col, tid)
+#define CSET(n, v) cf_set_##n(R, s_col, tid, (v))
+
+__global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
 {
   elmk_math_lds_init<true>();
+  __shared__ CfLds s_col[CF_NLDS];
+  __shared__ double s_pft[ELMK_MXPFT * PFT_STRIDE];
+  __shared__ FvConst s_fv;  // (in LDS, not in registers: kernel-lifetime constants would be the first thing spilled)
+  if (threadIdx.x < ELMK_MXPFT) cf_pft_row(S, threadIdx.x, s_pft + threadIdx.x * PFT_STRIDE);
+  if (threadIdx.x == 64) s_fv = fv_const();
+  __syncthreads();
   const int64_t ld = S->ld;
   const Land L = S->land;
+  const int tid = threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool soy = (L.vtype == pft_nsoybean || L.vtype == pft_nsoybeanirrig);
-  const FvConst FV = fv_const();
   const uint32_t nq = ELMK_LIST_COUNT(S, LIST_CF_QUEUE);  // final: written by k_cf_init
   bool exhausted = false;  // wave-uniform: the queue is empty
   int64_t pos = -1;        // queue position owned by this lane (-1: idle)
@@ -816,19 +883,17 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   uint32_t last_base = 0;              // queue head as this wave last saw it
   const uint32_t nwaves_total = gridDim.x * (blockDim.x >> 6);
 
-  CfRec in;
-  PsnInv I;
-  const double* __restrict__ P = nullptr;
+  CfRegs R;
+#define X(n) R.n = 0.0;
+  CF_REG_FIELDS(X)
+#undef X
+  const double* PR = s_pft;  // the column's PFT row
   int nrad = 0, fvn = 0;
-  bool day = false;
-  double forc_po2 = 0.0, forc_pco2 = 0.0, zldis = 0.0;
+  bool day = false, c3flag = true, same_tq = true;
   uint32_t err = 0;
   // loop-carried state of stability_iteration
   double t_veg = 0.0, btran = 0.0, um = 0.0, obu = 0.0, taf = 0.0, qaf = 0.0, el = 0.0, qsatl = 0.0, qsatldT = 0.0;
-  double dth = 0.0, dqh = 0.0, delq = 0.0, del = 0.0, efeb = 0.0, obuold = 0.0;
-  double qflx_tran_veg = 0.0, qflx_evap_veg = 0.0, eflx_sh_veg = 0.0;
-  double wtg = 0.0, wtl0 = 0.0, wta0 = 0.0, wtal = 0.0, wtgq = 0.0, wtalq = 0.0, wtlq0 = 0.0, wtaq0 = 0.0;
-  double temp1 = 0.0, temp2 = 0.0, tlbef = 0.0, dt_veg = 0.0;
+  double delq = 0.0, del = 0.0, efeb = 0.0, obuold = 0.0;
   int itlef = 0, nmozsgn = 0;
 #if CF_PROBE >= 4  // per-wave timeline: start, queue-exhausted and end time (100 MHz ticks), trips, active lane-trips
   const uint64_t pr_t0 = wall_clock64();
@@ -855,7 +920,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
     if (nidle >= CF_REFILL_MIN && (!exhausted || blk_next < blk_end)) {
       const bool take = (pos < 0);
       const unsigned long long m = __ballot(take);
-      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));  // set bits of m below this lane
       // positions come from the wave's private block first; one atomic on the queue head claims the next block
       // (what this refill still needs + CF_BLOCK_EXTRA for the refills to come): the atomic's round trip is then
       // paid by one refill in three or four instead of by every one
@@ -869,7 +934,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         const uint32_t extra = (nq - last_base > (uint32_t)CF_BLOCK_EXTRA * nwaves_total) ? (uint32_t)CF_BLOCK_EXTRA : 0u;
         const uint32_t want = need + extra;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE), want);
+        if (lane == 0) base = atomicAdd(ELMK_GENERIC(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE)), want);
         base = __shfl(base, 0, 64);
         last_base = (base < nq) ? base : nq;
         const uint32_t b1 = (base + want < nq) ? base + want : nq;
@@ -893,71 +958,69 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
     }
     if (fresh) {
       fresh = false;
-      const double* __restrict__ rec = S->cf_rec + CF_REC_BASE(pos);
-#define X(n) in.n = rec[REC_##n * 8];
-      CF_REC_FIELDS(X)
-#undef X
-      const int32_t* __restrict__ irec = S->cf_irec + pos;
-      P = S->pft_psn[irec[(int64_t)IREC_vtype * ld]];
+      const gptr<const double> rec = S->cf_rec + CF_REC_BASE(pos);
+#define LD(n) rec[REC_##n * 8]
+      const gptr<const int32_t> irec = S->cf_irec + pos;
+      const int vtype = irec[(int64_t)IREC_vtype * ld];
       nrad = irec[(int64_t)IREC_nrad * ld];
       fvn = irec[(int64_t)IREC_fvn * ld];
-      day = (nrad > 0) && (in.parsun > 0.0 || in.parsha > 0.0);
-      forc_po2 = derive_forc_po2(in.forc_pbot);
-      forc_pco2 = derive_forc_pco2(in.forc_pbot);
-      zldis = in.hgt_u - in.displa;
-      I.c3flag = (round(P[P_c3psn]) == 1);
-      I.lmrha = P[P_lmrha];
-      I.lmrhd = P[P_lmrhd];
-      I.lmrse = P[P_lmrse];
-      I.vcmaxha = P[P_vcmaxha];
-      I.vcmaxhd = P[P_vcmaxhd];
-      I.jmaxha = P[P_jmaxha];
-      I.jmaxhd = P[P_jmaxhd];
-      I.tpuha = P[P_tpuha];
-      I.tpuhd = P[P_tpuhd];
-      I.kcha = P[P_kcha];
-      I.koha = P[P_koha];
-      I.cpha = P[P_cpha];
-      I.vcmax25top = in.vcmax25top;
-      I.jmax25top = in.jmax25top;
-      I.tpu25top = in.tpu25top;
-      I.kp25top = in.kp25top;
-      I.lmr25top = in.lmr25top;
-      I.vcmaxse = in.vcmaxse;
-      I.jmaxse = in.jmaxse;
-      I.tpuse = in.vcmaxse;
-      I.vcmaxc = in.vcmaxc;
-      I.jmaxc = in.jmaxc;
-      I.tpuc = in.tpuc;
-      I.lmrc = in.lmrc;
-      I.cf = in.cf;
-      I.kc25 = (404.9 / 1.e06) * in.forc_pbot;
-      I.ko25 = (278.4 / 1.e03) * in.forc_pbot;
-      I.cp25 = in.cp25;
-      I.qe = in.qe;
-      I.theta_cj = in.theta_cj;
-      I.bbbopt = in.bbbopt;
-      I.mbbopt = in.mbbopt;
+      PR = s_pft + vtype * PFT_STRIDE;
+      c3flag = PR[PFT_c3] != 0.0;
+      const double pbot = LD(forc_pbot), thm = LD(thm), t_grnd = LD(t_grnd), forc_q = LD(forc_q), qg = LD(qg);
+      const double elai = LD(elai), esai = LD(esai), t10 = LD(t10), parsun = LD(parsun), parsha = LD(parsha);
+      const double displa = LD(displa), hgt_t = LD(hgt_t), hgt_q = LD(hgt_q);
+      CSET(forc_pbot, pbot);
+      CSET(thm, thm);
+      CSET(t_grnd, t_grnd);
+      CSET(forc_q, forc_q);
+      CSET(qg, qg);
+      CSET(elai, elai);
+      CSET(elai_esai, elai + esai);
+      CSET(parsun, parsun);
+      CSET(parsha, parsha);
+#define CP(n) CSET(n, LD(n));
+      CP(forc_th) CP(forc_rho) CP(thv) CP(z0mg) CP(z0mv) CP(ur) CP(htop) CP(fwet) CP(fdry) CP(laisun) CP(laisha) CP(rdl_num)
+      CP(soilbeta) CP(bir) CP(vcmaxcintsun) CP(vcmaxcintsha) CP(lai_sun_z) CP(lai_sha_z) CP(vcmaxc) CP(jmaxc) CP(tpuc)
+#undef CP
+      // operands that only ever enter a trip combined, combined once (same operations in the same order as the trip's
+      // expressions: hgt - displa of the three profiles :235-238, sabv + air and cir * lw_grnd of :391-392 / :399-401,
+      // h2ocan / dtime of :338 / :411-412)
+      CSET(zl_u, LD(hgt_u) - displa);
+      CSET(zl_t, hgt_t - displa);
+      CSET(zl_q, (hgt_q == hgt_t) ? (hgt_t - displa) : (hgt_q - displa));
+      same_tq = (hgt_q == hgt_t);
+      CSET(rad_in, LD(sabv) + LD(air));
+      CSET(lw_term, LD(cir) * LD(lw_grnd));
+      CSET(h2ocan_dt, LD(h2ocan) / dtime);
+      day = (nrad > 0) && (parsun > 0.0 || parsha > 0.0);
+      // what k_cf_init does not hand over: a few instructions each, from the record's own fields
+      CSET(w_lai, elmk_exp(-(elai + esai)));  // (canopy_fluxes_impl.hh:272)
+      {
+        // iteration-invariant part of photosynthesis() (photosynthesis_impl.hh:35-37, :46-50, :91, :152-154)
+        CSET(tc10, dmin(dmax((t10 - TFRZ), 11.0), 35.0));
+        CSET(cf, pbot / (RGAS * 1.0e-3 * thm) * 1.e06);
+        const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
+        CSET(cp25, 0.5 * derive_forc_po2(pbot) / sco);
+      }
       // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
-      btran = in.btran;
-      t_veg = in.t_veg;
-      el = in.el;
-      qsatl = in.qsatl;
-      qsatldT = in.qsatldT;
-      taf = (in.t_grnd + in.thm) / 2.0;
-      qaf = (in.forc_q + in.qg) / 2.0;
-      delq = in.qg - qaf;
-      um = in.um;
-      obu = in.obu;
+      btran = LD(btran);
+      t_veg = LD(t_veg);
+      um = LD(um);
+      obu = LD(obu);
+#undef LD
+      {
+        double deldT;
+        qsat(t_veg, pbot, el, deldT, qsatl, qsatldT);
+      }
+      taf = (t_grnd + thm) / 2.0;
+      qaf = (forc_q + qg) / 2.0;
+      delq = qg - qaf;
       del = 0.0;
       efeb = 0.0;
       obuold = 0.0;
       itlef = 0;
       nmozsgn = 0;
       err = 0;
-      qflx_tran_veg = 0.0;  // assigned on every path of the first trip before it is read
-      qflx_evap_veg = 0.0;
-      eflx_sh_veg = 0.0;
     }
     if (__ballot(pos >= 0) == 0ull) {
       if (exhausted && blk_next >= blk_end) break;
@@ -969,107 +1032,156 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
     pr_lanes += (uint64_t)__popcll(__ballot(pos >= 0));
 #endif
 
+    // A wave that carries a column deep into its iteration is on the kernel's critical path (the slowest columns take the
+    // 41-trip limit, and often Brent's method in every trip: a millisecond of dependent work on their own): it gets issue
+    // priority over the wave it shares the SIMD with, which then fills the gaps instead of competing for the slots.
+    if (__ballot(pos >= 0 && itlef >= CF_PRIO_TRIPS) != 0ull) {
+      __builtin_amdgcn_s_setprio(2);
+    } else {
+      __builtin_amdgcn_s_setprio(0);
+    }
+
     // ---------------- one trip of the leaf-temperature iteration (:233-450) ----------------
     if (pos >= 0) {
-      double ustar, unused12m = 0.0, unused22m = 0.0;
+      double ustar, temp1, temp2, unused12m = 0.0, unused22m = 0.0;
       const double obu_trip = obu;
+      const double zldis = C(zl_u);
       // the 2 m profiles (:239-240) are only read by compute_flux: k_cf_finish evaluates them from obu_trip
-      friction_profiles<true, false>(in.hgt_u, in.hgt_t, in.hgt_q, in.displa, um, obu, in.z0mv, in.z0mv, in.z0mv, FV, ustar,
-                                     temp1, temp2, unused12m, unused22m);
+      {
+        const double z0mv = C(z0mv);
+        friction_profiles_zl<true, false>(zldis, C(zl_t), C(zl_q), same_tq, um, obu, z0mv, z0mv, z0mv, s_fv, ustar, temp1, temp2,
+                                          unused12m, unused22m);
+      }
       PR_T(1)
-      tlbef = t_veg;
+      const double tlbef = t_veg;
       const double del2 = del;
       const double ram = 1.0 / (ustar * ustar / um);
       const double rah0 = 1.0 / (temp1 * ustar);
       const double raw0 = 1.0 / (temp2 * ustar);
       const double uaf = um * sqrt(1.0 / (ram * um));
-      const double cf = 0.01 / (sqrt(uaf) * in.sqrt_dleaf);
+      const double cf = 0.01 / (sqrt(uaf) * PR[PFT_sqrt_dleaf]);
       const double rb = 1.0 / (cf * uaf);
-      const double w = in.w_lai;
-      const double csoilb = (VKC / (0.13 * elmk_pow((in.z0mg * uaf / 1.5e-5), 0.45)));
-      const double ri = (GRAV * in.htop * (taf - in.t_grnd)) / (taf * elmk_sq(uaf));
-      double csoilcn;
-      if ((taf - in.t_grnd) > 0.0) {
-        const double ricsoilc = CSOILC / (1.0 + 0.5 * dmin(ri, 10.0));
-        csoilcn = csoilb * w + ricsoilc * (1.0 - w);
-      } else {
-        csoilcn = csoilb * w + CSOILC * (1.0 - w);
+      double rah1;
+      {
+        const double w = C(w_lai);
+        const double csoilb = (VKC / (0.13 * elmk_pow((C(z0mg) * uaf / 1.5e-5), 0.45)));
+        const double ri = (GRAV * C(htop) * (taf - C(t_grnd))) / (taf * elmk_sq(uaf));
+        double csoilcn;
+        if ((taf - C(t_grnd)) > 0.0) {
+          const double ricsoilc = CSOILC / (1.0 + 0.5 * dmin(ri, 10.0));
+          csoilcn = csoilb * w + ricsoilc * (1.0 - w);
+        } else {
+          csoilcn = csoilb * w + CSOILC * (1.0 - w);
+        }
+        rah1 = 1.0 / (csoilcn * uaf);
       }
-      const double rah1 = 1.0 / (csoilcn * uaf);
       const double raw1 = rah1;
       const double svpts = el;
-      const double eah = in.forc_pbot * qaf / 0.622;
+      const double eah = C(forc_pbot) * qaf / 0.622;
 
-      // temperature factors of this trip, shared by both phases
-      const PsnTemp T = psn_temp(I, P, t_veg, day);
-
-      PR_T(2)
-      if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssun = psn_phase(I, T, nrad, in.forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, in.vcmaxcintsun,
-                                     in.parsun, in.lai_sun_z, err);
-      PR_T(3)
-      if (soy) btran = dmin(1.0, btran * 1.25);
-      const double rssha = psn_phase(I, T, nrad, in.forc_pbot, svpts, eah, forc_po2, forc_pco2, rb, btran, in.vcmaxcintsha,
-                                     in.parsha, in.lai_sha_z, err);
+      double rssun, rssha;
+      {
+        PsnPhaseIn qsun, qsha;
+        PsnSolveIn J;
+        double btran_sun, btran_sha;
+        {
+          // temperature factors of this trip, shared by both phases; consumed here for both
+          const double tc = C(tc10);
+          const PsnTemp T = psn_temp(PR, c3flag, 668.39 - 1.07 * tc, 659.70 - 0.75 * tc, C(vcmaxc), C(jmaxc), C(tpuc),
+                                     (404.9 / 1.e06) * C(forc_pbot), (278.4 / 1.e03) * C(forc_pbot), C(cp25), t_veg, day);
+          PsnCol I;
+          I.c3flag = c3flag;
+          I.vcmax25top = PR[PFT_vcmax25top];
+          I.jmax25top = (2.59 - 0.035 * tc) * PR[PFT_vcmax25top];
+          I.cf = 0.0;  // (not read by psn_phase_inputs)
+          I.qe = I.theta_cj = I.bbbopt = I.mbbopt = 0.0;
+          // the soybean adjustment of btran runs once in front of each phase (:282-292), so the shaded phase sees it twice
+          if (soy) btran = dmin(1.0, btran * 1.25);
+          btran_sun = btran;
+          if (soy) btran = dmin(1.0, btran * 1.25);
+          btran_sha = btran;
+          qsun = psn_phase_inputs(I, T, btran_sun, C(vcmaxcintsun), C(parsun));
+          qsha = psn_phase_inputs(I, T, btran_sha, C(vcmaxcintsha), C(parsha));
+          J.cp = T.cp;
+          J.kc = T.kc;
+          J.ko = T.ko;
+        }
+        J.c3flag = c3flag;
+        J.cf = C(cf);
+        J.qe = PR[PFT_qe];
+        J.theta_cj = PR[PFT_theta_cj];
+        J.bbbopt = PR[PFT_bbbopt];
+        J.mbbopt = PR[PFT_mbbopt];
+        const double forc_po2 = derive_forc_po2(C(forc_pbot)), forc_pco2 = derive_forc_pco2(C(forc_pbot));
+        PR_T(2)
+        rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
+                                C(lai_sun_z), err);
+        PR_T(3)
+        rssha = psn_phase_solve(J, qsha, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sha, C(parsha),
+                                C(lai_sha_z), err);
+      }
       PR_T(4)
 #if CF_PROBE >= 4
       pr_brent += (uint64_t)__popcll(__ballot((err & 0x80000000u) != 0u));
       pr_brent_trips += (__ballot((err & 0x80000000u) != 0u) != 0ull) ? 1u : 0u;
-      pr_c4 += (__ballot(!I.c3flag) != 0ull) ? 1u : 0u;
+      pr_c4 += (__ballot(!c3flag) != 0ull) ? 1u : 0u;
       pr_day += (uint64_t)__popcll(__ballot(day));
       err &= 0x7FFFFFFFu;
 #endif
 
       const double wta = 1.0 / rah0;
-      const double wtl = (in.elai + in.esai) / rb;
-      wtg = 1.0 / rah1;
+      const double wtl = C(elai_esai) / rb;
+      const double wtg = 1.0 / rah1;
       const double wtshi = 1.0 / (wta + wtl + wtg);
-      wtl0 = wtl * wtshi;
+      const double wtl0 = wtl * wtshi;
       const double wtg0 = wtg * wtshi;
-      wta0 = wta * wtshi;
+      const double wta0 = wta * wtshi;
       const double wtga = wta0 + wtg0;
-      wtal = wta0 + wtl0;
+      const double wtal = wta0 + wtl0;
 
       double rppdry;
-      if (in.fdry > 0.0) {
-        rppdry = in.fdry * rb * (in.laisun / (rb + rssun) + in.laisha / (rb + rssha)) / in.elai;
+      if (C(fdry) > 0.0) {
+        rppdry = C(fdry) * rb * (C(laisun) / (rb + rssun) + C(laisha) / (rb + rssha)) / C(elai);
       } else {
         rppdry = 0.0;
       }
-      double efpot = in.forc_rho * wtl * (qsatl - qaf);
-      double rpp;
+      const double forc_rho = C(forc_rho);
+      const double h2ocan_dt = C(h2ocan_dt);
+      double efpot = forc_rho * wtl * (qsatl - qaf);
+      double rpp, qflx_tran_veg;
       if (efpot > 0.0) {
         if (btran > 0.0) {
           qflx_tran_veg = efpot * rppdry;
-          rpp = rppdry + in.fwet;
+          rpp = rppdry + C(fwet);
         } else {
-          rpp = in.fwet;
+          rpp = C(fwet);
           qflx_tran_veg = 0.0;
         }
-        rpp = dmin(rpp, (qflx_tran_veg + in.h2ocan / dtime) / efpot);
+        rpp = dmin(rpp, (qflx_tran_veg + h2ocan_dt) / efpot);
       } else {
         rpp = 1.0;
         qflx_tran_veg = 0.0;
       }
 
       const double wtaq = fvn / raw0;
-      const double wtlq = fvn * (in.elai + in.esai) / rb * rpp;
-      const double rdl = in.rdl_num / (0.004 * uaf);
+      const double wtlq = fvn * C(elai_esai) / rb * rpp;
+      const double rdl = C(rdl_num) / (0.004 * uaf);
+      double wtgq;
       if (delq < 0.0) {
         wtgq = fvn / (raw1 + rdl);
       } else {
-        wtgq = in.soilbeta * fvn / (raw1 + rdl);
+        wtgq = C(soilbeta) * fvn / (raw1 + rdl);
       }
       const double wtsqi = 1.0 / (wtaq + wtlq + wtgq);
       const double wtgq0 = wtgq * wtsqi;
-      wtlq0 = wtlq * wtsqi;
-      wtaq0 = wtaq * wtsqi;
+      const double wtlq0 = wtlq * wtsqi;
+      const double wtaq0 = wtaq * wtsqi;
       const double wtgaq = wtaq0 + wtgq0;
-      wtalq = wtaq0 + wtlq0;
-      const double dc1 = in.forc_rho * CPAIR * wtl;
-      const double dc2 = HVAP * in.forc_rho * wtlq;
-      const double efsh = dc1 * (wtga * t_veg - wtg0 * in.t_grnd - wta0 * in.thm);
-      double efe = dc2 * (wtgaq * qsatl - wtgq0 * in.qg - wtaq0 * in.forc_q);
+      const double wtalq = wtaq0 + wtlq0;
+      const double dc1 = forc_rho * CPAIR * wtl;
+      const double dc2 = HVAP * forc_rho * wtlq;
+      const double efsh = dc1 * (wtga * t_veg - wtg0 * C(t_grnd) - wta0 * C(thm));
+      double efe = dc2 * (wtgaq * qsatl - wtgq0 * C(qg) - wtaq0 * C(forc_q));
 
       double erre = 0.0;
       if ((efe * efeb) < 0.0) {
@@ -1078,8 +1190,11 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
         erre = efe - efeold;
       }
       const double tveg3 = elmk_pow(t_veg, 3.0);  // t_veg == tlbef here: also the pow(tlbef, 3.0) of errv below (:399)
-      dt_veg = (in.sabv + in.air + in.bir * elmk_pow(t_veg, 4.0) + in.cir * in.lw_grnd - efsh - efe) /
-               (-4.0 * in.bir * tveg3 + dc1 * wtga + dc2 * wtgaq * qsatldT);
+      const double rad_in = C(rad_in);
+      const double lw_term = C(lw_term);
+      const double bir = C(bir);
+      double dt_veg = (rad_in + bir * elmk_pow(t_veg, 4.0) + lw_term - efsh - efe) /
+                      (-4.0 * bir * tveg3 + dc1 * wtga + dc2 * wtgaq * qsatldT);
       t_veg = tlbef + dt_veg;
       const double dels = dt_veg;
       del = fabs(dels);
@@ -1087,38 +1202,38 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       if (del > 1.0) {
         dt_veg = dels / del;
         t_veg = tlbef + dt_veg;
-        errv = in.sabv + in.air + in.bir * tveg3 * (tlbef + 4.0 * dt_veg) + in.cir * in.lw_grnd -
-               (efsh + dc1 * wtga * dt_veg) - (efe + dc2 * wtgaq * qsatldT * dt_veg);
+        errv = rad_in + bir * tveg3 * (tlbef + 4.0 * dt_veg) + lw_term - (efsh + dc1 * wtga * dt_veg) -
+               (efe + dc2 * wtgaq * qsatldT * dt_veg);
       }
-      efpot = in.forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * in.qg - wtaq0 * in.forc_q);
-      qflx_evap_veg = rpp * efpot;
+      efpot = forc_rho * wtl * (wtgaq * (qsatl + qsatldT * dt_veg) - wtgq0 * C(qg) - wtaq0 * C(forc_q));
+      double qflx_evap_veg = rpp * efpot;
       if (efpot > 0.0 && btran > 0.0) {
         qflx_tran_veg = efpot * rppdry;
       } else {
         qflx_tran_veg = 0.0;
       }
-      const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - in.h2ocan / dtime);
-      qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + in.h2ocan / dtime);
-      eflx_sh_veg = efsh + dc1 * wtga * dt_veg + errv + erre + HVAP * ecidif;
+      const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - h2ocan_dt);
+      qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + h2ocan_dt);
+      const double eflx_sh_veg = efsh + dc1 * wtga * dt_veg + errv + erre + HVAP * ecidif;
       double deldT;
-      qsat(t_veg, in.forc_pbot, el, deldT, qsatl, qsatldT);
+      qsat(t_veg, C(forc_pbot), el, deldT, qsatl, qsatldT);
 
-      taf = wtg0 * in.t_grnd + wta0 * in.thm + wtl0 * t_veg;
-      qaf = wtlq0 * qsatl + wtgq0 * in.qg + in.forc_q * wtaq0;
-      dth = in.thm - taf;
-      dqh = in.forc_q - qaf;
-      delq = wtalq * in.qg - wtlq0 * qsatl - wtaq0 * in.forc_q;
+      taf = wtg0 * C(t_grnd) + wta0 * C(thm) + wtl0 * t_veg;
+      qaf = wtlq0 * qsatl + wtgq0 * C(qg) + C(forc_q) * wtaq0;
+      const double dth = C(thm) - taf;
+      const double dqh = C(forc_q) - qaf;
+      delq = wtalq * C(qg) - wtlq0 * qsatl - wtaq0 * C(forc_q);
       const double tstar = temp1 * dth;
       const double qstar = temp2 * dqh;
-      const double thvstar = tstar * (1.0 + 0.61 * in.forc_q) + 0.61 * in.forc_th * qstar;
-      double zeta = zldis * VKC * GRAV * thvstar / (elmk_sq(ustar) * in.thv);
+      const double thvstar = tstar * (1.0 + 0.61 * C(forc_q)) + 0.61 * C(forc_th) * qstar;
+      double zeta = zldis * VKC * GRAV * thvstar / (elmk_sq(ustar) * C(thv));
       if (zeta >= 0.0) {
         zeta = dmin(2.0, dmax(zeta, 0.01));
-        um = dmax(in.ur, 0.1);
+        um = dmax(C(ur), 0.1);
       } else {
         zeta = dmax(-100.0, dmin(zeta, -0.01));
-        const double wc = 1.0 * elmk_pow((-GRAV * ustar * thvstar * 1000.0 / in.thv), 0.333);
-        um = sqrt(in.ur * in.ur + wc * wc);
+        const double wc = 1.0 * elmk_pow((-GRAV * ustar * thvstar * 1000.0 / C(thv)), 0.333);
+        um = sqrt(C(ur) * C(ur) + wc * wc);
       }
       obu = zldis / zeta;
       if (obuold * obu < 0.0) nmozsgn += 1;
@@ -1138,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
       PR_T(5)
       // ---------------- converged: hand the state to k_cf_finish, release the lane ----------------
       if (stop) {
-        double* __restrict__ fin = S->cf_fin + CF_FIN_BASE(pos);
+        const gptr<double> fin = S->cf_fin + CF_FIN_BASE(pos);
         fin[FIN_t_veg * 8] = t_veg;
         fin[FIN_btran * 8] = btran;
         fin[FIN_qflx_tran_veg * 8] = qflx_tran_veg;
@@ -1173,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   }
 #if CF_PROBE >= 4
   if (lane == 0) {
-    double* o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const gptr<double> o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
 #if CF_PROBE == 5
     for (int i = 0; i < 4; i++) o[8 + i] = (double)(pr_acc[2 * i] + pr_acc[2 * i + 1]);
 #endif
@@ -1192,6 +1307,8 @@ __global__ __launch_bounds__(256) void k_cf_iterate(const DevState* __restrict__
   }
 #endif
 }
+#undef C
+#undef CSET
 
 // =====================================================================================================
 // k_cf_finish - one thread per column, coalesced: compute_flux (canopy_fluxes_impl.hh:456-540) from the converged
@@ -1207,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   const int32_t pos = S->cf_pos[c];
   if (pos < 0) return;
   CfFin f;
-  const double* __restrict__ fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
+  const gptr<const double> fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
 #define X(n) f.n = fin[FIN_##n * 8];
   CF_FIN_FIELDS(X)
 #undef X
@@ -1283,10 +1400,10 @@ void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t s
   const unsigned nblk = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cf_count, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S);
   hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S);
-  // persistent: one wave per SIMD is resident at this kernel's register footprint (256 workgroups); workgroups that
-  // start later find the queue empty
+  // persistent: two waves per SIMD are resident at this kernel's register and LDS footprint (2 workgroups per CU, 512 in
+  // all); workgroups that start later find the queue empty
   unsigned groups = nblk < 512u ? nblk : 512u;
-  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(256), 0, st, S, dt);
+  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt);
   hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt);
 }
 

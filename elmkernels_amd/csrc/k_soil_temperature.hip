@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void k_st_props(const DevState* __restrict__ S
 constexpr int ST_ROW_A = 2 * NLEVTOT;        // rows of st_work after thk, cv
 constexpr int ST_ROW_Z = 2 * NLEVTOT + NROW;
 struct StSweep {
-  double* __restrict__ A;  // scratch bases of this column; element of row r at [r * ld]
-  double* __restrict__ Z;
+  gptr<double> A;  // scratch bases of this column; element of row r at [r * ld]
+  gptr<double> Z;
   double B4;  // B of row NLEVSNO - 1
   double Am2, Am1, Bm2, Bm1, Zm2, Zm1;
   double Y1, U1, r19, l4_19, A19;  // kept from the second row from the bottom for the reference's form of the last two
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
   w.Am2 = w.Am1 = w.Bm2 = w.Bm1 = w.Zm2 = w.Zm1 = 0.0;
   w.Y1 = w.U1 = w.r19 = w.l4_19 = w.A19 = 0.0;
   double fact_sl1 = 0.0;  // matrix factor of the snow layer next to the ground (for phase_change_h2osfc)
-  const double* __restrict__ props = S->st_work + c;  // stage 1 (k_st_props): rows ST_ROW_THK + i, ST_ROW_CV + i
+  const gptr<const double> props = S->st_work + c;  // stage 1 (k_st_props): rows ST_ROW_THK + i, ST_ROW_CV + i
   double thk_cur = props[(int64_t)ST_ROW_THK * ld], cv_cur = props[(int64_t)ST_ROW_CV * ld];
   double z_cur = LV(zsoi, 0), t_cur = LV(t_soisno, 0);
   double z_prev = 0.0, tk_prev = 0.0, fn_prev = 0.0;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_conservation(const DevState* __restrict
   const int64_t ld = S->ld;
   if (c >= S->ncols) return;
   const double hydrology_source_sink = 0.0;  // hardwired (:22)
-  double* __restrict__ d = S->cons_diag + c;
+  const gptr<double> d = S->cons_diag + c;
   const double h2osno = S->h2osno[c];
   double water = S->h2ocan[c] + h2osno + S->h2osfc[c];  // column_water_mass (:7-15)
 #pragma unroll 1

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_surface_radiation(const DevState* __res
       err_sum += lyr[j];
       LV(sabg_lyr, j) = lyr[j];
     }
-    if (fabs(err_sum - sabg_snow) > 0.00001) atomicOr(&S->err_flags[c], ELMK_ERR_SURFRAD_LAYER_SUM);
+    if (fabs(err_sum - sabg_snow) > 0.00001) atomicOr(ELMK_GENERIC(&S->err_flags[c]), ELMK_ERR_SURFRAD_LAYER_SUM);
   }
 
   // ---- reflected_radiation (:179-199)
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
 {
   const int64_t ld = S->ld;
   const uint32_t count = ELMK_LIST_COUNT(S, LIST_BG);
-  const int32_t* __restrict__ list = S->lists + (int64_t)LIST_BG * ld;
+  const gptr<const int32_t> list = S->lists + (int64_t)LIST_BG * ld;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
   const int64_t c = list[q];
 

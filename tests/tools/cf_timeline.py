@@ -36,7 +36,7 @@ for name, m in (("day", veg & day), ("night", veg & ~day)):
     print(name, "mean trips %.2f" % t.mean(), "hist", {i: int(v) for i, v in enumerate(h) if v})
 ld = D.level_stride
 WK_DEBUG = 1
-nw = 2048
+nw = 4096
 w = D.read_work(WK_DEBUG * ld, nw * 16).reshape(nw, 16)
 w = w[w[:, 7] == 1.0]
 if len(w):

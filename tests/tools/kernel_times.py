@@ -12,7 +12,7 @@ tiers = sys.argv[2] if len(sys.argv) > 2 else "AB"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 for tier in tiers:
     D, _ = bench.build_state(cols, 0, tier, 0x5EEDE1A0)
-    for _ in range(2):
+    for _ in range(int(os.environ.get("KT_WARM", "8"))):  # the canopy_fluxes scheduling hints settle over a few steps
         D.restore_fields()
         st.timestep7(D, 1800.0)
     D.restore_fields()

@@ -46,6 +46,8 @@ SIGNATURES = {
     "elmk_bareground_fluxes": (C.c_int, [_P]),
     "elmk_canopy_fluxes": (C.c_int, [_P, C.c_double]),
     "elmk_timestep7": (C.c_int, [_P, C.c_double]),
+    "elmk_timestep7_fused": (C.c_int, [_P, C.c_double]),
+    "elmk_profile_timestep7_fused": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_soil_temperature": (C.c_int, [_P, C.c_double]),
     "elmk_surface_fluxes": (C.c_int, [_P, C.c_double]),
     "elmk_init_timestep": (C.c_int, [_P]),

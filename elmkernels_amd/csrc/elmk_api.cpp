@@ -219,10 +219,11 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t irec_bytes = align_up((size_t)CF_IREC_N * (size_t)ctx->ld * 4, 256);
   const size_t pos_bytes = align_up((size_t)ctx->ld * 4, 256);
   const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
+  const size_t cls_bytes = align_up((size_t)ctx->ld, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
   const size_t stw_bytes = align_up((size_t)(40 + 42) * (size_t)ctx->ld * 8, 256);  // soil_temperature: thk, cv of the 20 levels; A, Z of the 21 rows
   const size_t cons_bytes = align_up((size_t)8 * (size_t)ctx->ld * 8 + (size_t)8 * ELMK_CONS_NPART * 3 * 8 + 8 * 3 * 8, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + snow_bytes + stw_bytes + cons_bytes;
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + cls_bytes + snow_bytes + stw_bytes + cons_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -261,6 +262,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     q += pos_bytes;
     h.cf_blk = (gptr<uint32_t>)q;
     q += blk_bytes;
+    h.cf_cls = (gptr<int8_t>)q;
+    q += cls_bytes;
     h.alb_snow = (gptr<double>)q;
     q += snow_bytes;
     h.st_work = (gptr<double>)q;
@@ -715,6 +718,8 @@ void launch_stage7(elmk_ctx* ctx, int k, double dt)
     default: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
   }
 }
+// elmk_timestep7_fused: the same seven wrappers as ELMK_FUSED_NSTAGE launch groups (k_canopy_fluxes.hip)
+void launch_stage_fused(elmk_ctx* ctx, int k, double dt) { launch_fused_stage(ctx->d, ctx->ncols, dt, ctx->stream, &ctx->side, k); }
 typedef void (*stage_fn)(elmk_ctx*, int, double);
 
 // all stages in order; marks (may be null): nstage + 1 events recorded around the stages on the context's stream
@@ -805,6 +810,13 @@ int elmk_timestep7(elmk_ctx* ctx, double dt)
   return enqueue_stages(ctx, launch_stage7, TS7_NSTAGE, dt, nullptr);
 }
 
+int elmk_timestep7_fused(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  if (ctx->use_graph) return run_graph(ctx, ctx->graph[1], launch_stage_fused, ELMK_FUSED_NSTAGE, dt);
+  return enqueue_stages(ctx, launch_stage_fused, ELMK_FUSED_NSTAGE, dt, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------------------
@@ -834,6 +846,13 @@ int elmk_profile_timestep7(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_k
   PHYSICS_PROLOGUE();
   if (nsteps <= 0) return invalid(ctx, "elmk_profile_timestep7: nsteps <= 0");
   return profile_stages(ctx, launch_stage7, TS7_NSTAGE, dt, nsteps, ms_per_kernel, ms_total);
+}
+
+int elmk_profile_timestep7_fused(elmk_ctx* ctx, double dt, int nsteps, float* ms_per_stage, float* ms_total)
+{
+  PHYSICS_PROLOGUE();
+  if (nsteps <= 0) return invalid(ctx, "elmk_profile_timestep7_fused: nsteps <= 0");
+  return profile_stages(ctx, launch_stage_fused, ELMK_FUSED_NSTAGE, dt, nsteps, ms_per_stage, ms_total);
 }
 
 namespace {

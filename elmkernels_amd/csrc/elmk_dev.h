@@ -194,6 +194,7 @@ struct DevState {
   gptr<double> cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position
   gptr<int32_t> cf_irec;    // CF_IREC_N x ld
   gptr<int32_t> cf_pos;     // queue position of each column (-1: not vegetated)
+  gptr<int8_t> cf_cls;      // scheduling class of each column as k_fz_prep counted it (fused step)
   gptr<uint32_t> cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
   int64_t cf_nblk;     // workgroups of 256 columns
 #define ELMK_FIELD(name, T, nlev) gptr<ctype_of<ELMK_##T>::type> name;

@@ -21,12 +21,20 @@ struct SideStreams {
 
 // the seven physics launches (one per reference L3 wrapper)
 void launch_frac_wet(const DevState* S, int64_t n, hipStream_t st);
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side);
+// reset_lists = false: the caller has zeroed the layer-count lists (the fused step does it in k_fz_prep)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool reset_lists = true);
 void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);
 void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+// elmk_timestep7_fused: the same seven wrappers as five launch groups (k_canopy_fluxes.hip):
+//   0 k_fz_prep (frac_wet, list resets, canopy_fluxes class count)   1 albedo_snicar   2 k_fz_stream (canopy_hydrology ->
+//   surface_radiation -> canopy_temperature -> bare-ground list -> canopy_fluxes initialize_flux, one pass per column)
+//   3 the bare-ground flux list   4 the leaf-temperature iteration and compute_flux
+constexpr int ELMK_FUSED_NSTAGE = 5;
+void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st, const SideStreams* side, int stage);
+void launch_bareground_list(const DevState* S, int64_t n, hipStream_t st);
 // next row after the seven: soil / snow column temperature
 void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st);
 // surface fluxes after the solve, conservation diagnostics reduced to (min, max, sum)

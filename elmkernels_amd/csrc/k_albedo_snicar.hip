@@ -777,7 +777,7 @@ __global__ void k_alb_reset(const DevState* __restrict__ S)
   }
 }
 
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool reset_lists)
 {
   if (n <= 0) return;
   const dim3 block(256);
@@ -785,7 +785,7 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   // stage 2 is grid-stride over a device-side count: 24 columns per workgroup
   const unsigned want = (unsigned)((n + 23) / 24);
   const unsigned capped = want < 4096u ? want : 4096u;
-  hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
+  if (reset_lists) hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
   hipLaunchKernelGGL(k_alb_classify, dim3(full), block, 0, st, S);
   // The five layer-count queues are independent: side streams let their launches overlap (fork/join with events).
   // (One persistent launch draining all five lists through a chunk counter was measured 30 % slower: every wave then

@@ -20,10 +20,10 @@
 #define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
+#include "elmk_stream.h"
 
 namespace elmk {
 
-#define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
 
 // photosynthesis_impl.hh:623-635
 __device__ __forceinline__ double psn_ft(double tl, double ha)
@@ -502,13 +502,9 @@ enum : int { IREC_vtype = 0, IREC_nrad, IREC_fvn };
 // (elmk_create clears them, k_cf_finish clears them again for the next call)
 #define CF_CLASS_COUNT(S, k) ((S)->counters[(2 * NLISTS + (k)) * CPAD])
 
-// scheduling class of a column, -1 if it is not vegetated (lake land units are handled by the callers)
-__device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const Land& L, int64_t c, bool inside)
+// scheduling class from (day, trip hint of the previous call: 0 = never iterated -> middle bin)
+__device__ __forceinline__ int cf_class_of(const bool day, const int prev)
 {
-  if (!inside || L.urbpoi) return -1;
-  if (S->frac_veg_nosno[c] == 0) return -1;
-  const bool day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
-  const int prev = S->cf_niter[c] >> 16;  // scheduling hint (see k_cf_finish); 0: never iterated -> middle bin
   int bin = 3;
   if (prev >= 22) {
     bin = 0;
@@ -529,6 +525,14 @@ __device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const La
   // (Separating C3 from C4 columns as well - 24 classes - was measured: no gain, the finer classes cost as much in
   // k_cf_init's scattered record writes and in queue tail as the C4 branches cost in mixed waves.)
   return (day ? 0 : CF_NCLS / 2) + bin;
+}
+// scheduling class of a column, -1 if it is not vegetated (lake land units are handled by the callers)
+__device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const Land& L, int64_t c, bool inside)
+{
+  if (!inside || L.urbpoi) return -1;
+  if (S->frac_veg_nosno[c] == 0) return -1;
+  const bool day = (S->nrad[c] > 0) && (S->parsun_z[c] > 0.0 || S->parsha_z[c] > 0.0);
+  return cf_class_of(day, S->cf_niter[c] >> 16);  // scheduling hint (see k_cf_finish)
 }
 
 // One workgroup counts CF_COUNT_TILES tiles of 256 columns (a tile = one workgroup of k_cf_init) and takes the
@@ -566,22 +570,12 @@ __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S
   }
 }
 
-__global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
+// Queue position of this thread's column: slice of (class, workgroup) from the count kernel (k_cf_count, or k_fz_prep in
+// the fused step), then (wave, lane) order inside the workgroup.  All 256 threads of the workgroup call it (one barrier);
+// cls < 0: not vegetated -> -1.  Thread 0 of workgroup 0 publishes the queue length.
+__device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict__ S, const int cls)
 {
-  elmk_math_lds_init<false>();
   __shared__ uint32_t s_w[4][CF_NCLS];
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t ld = S->ld;
-  const Land L = S->land;
-  if (L.lakpoi) {  // uniform: the wrapper does nothing on lake land units
-    if (blockIdx.x == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
-    return;
-  }
-  const bool inside = c < S->ncols;
-  const int cls = cf_class(S, L, c, inside);
-  const bool veg = cls >= 0;
-
-  // queue position: slice of (class, workgroup) from k_cf_count, then (wave, lane) order inside the workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t rank = 0u;
 #pragma unroll
@@ -592,37 +586,43 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   }
   __syncthreads();
   int64_t pos = -1;
-  {
-    // start of each class in the queue = total of the classes before it (final: k_cf_count has completed)
-    uint32_t start = 0u, mine = 0u;
+  // start of each class in the queue = total of the classes before it (final: the count kernel has completed)
+  uint32_t start = 0u, mine = 0u;
 #pragma unroll
-    for (int k = 0; k < CF_NCLS; k++) {
-      if (k == cls) mine = start;
-      start += CF_CLASS_COUNT(S, k);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = start;
-      ELMK_LIST_HEAD(S, LIST_CF_QUEUE) = 0u;
-    }
-    if (veg) {
-      uint32_t off = mine + S->cf_blk[(int64_t)cls * S->cf_nblk + blockIdx.x];
-      for (int w = 0; w < wave; w++) off += s_w[w][cls];
-      pos = (int64_t)off + rank;
-    }
+  for (int k = 0; k < CF_NCLS; k++) {
+    if (k == cls) mine = start;
+    start += CF_CLASS_COUNT(S, k);
   }
-  if (inside) S->cf_pos[c] = (int32_t)pos;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = start;
+    ELMK_LIST_HEAD(S, LIST_CF_QUEUE) = 0u;
+  }
+  if (cls >= 0) {
+    uint32_t off = mine + S->cf_blk[(int64_t)cls * S->cf_nblk + blockIdx.x];
+    for (int w = 0; w < wave; w++) off += s_w[w][cls];
+    pos = (int64_t)off + rank;
+  }
+  return pos;
+}
 
+// canopy_fluxes for one column up to the iteration: the bare branch, or initialize_flux (canopy_fluxes_impl.hh:95-184) and the
+// queue record.  One source for k_cf_init (inputs from the state) and the fused streaming stage (FUSED: the values the
+// earlier bodies of the same pass produced come through ColFwd).  pos: the column's queue position (-1: not vegetated).
+template <bool FUSED>
+__device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                            const int64_t pos, const ColFwd& w)
+{
+  const bool inside = true, veg = pos >= 0;
   if (inside && !veg) {
     S->cf_niter[c] &= (int32_t)0xFFFF0000;  // trips of this call: 0 (not vegetated); the scheduling hint stays
     if (!L.urbpoi) {
       S->btran[c] = 0.0;
-      S->t_veg[c] = S->forc_tbot[c];
+      S->t_veg[c] = FW(forc_tbot, S->forc_tbot[c]);
 #pragma unroll
       for (int i = 0; i < NLEVGRND; i++) LV(rootr, i) = 0.0;
     }
-    S->cgrnd[c] = 0.0;
-    S->cgrnds[c] = 0.0;
-    S->cgrndl[c] = 0.0;
+    // (the cgrnd* = 0 of this branch, compute_flux :470-474, is written by k_cf_finish: in the fused step this body runs
+    // BEFORE the bare-ground flux list, whose cgrnd* of the same columns the reference's call order overwrites)
   }
   if (!veg) return;
 
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   CfRec r;
   const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
 #define PUT(n) rec[REC_##n * 8] = r.n;
-  const int snl = S->snl[c];
+  const int snl = FW(snl, S->snl[c]);
   const int vtype = S->vtype[c];
   const double* __restrict__ P = S->pft_psn[vtype];
   const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
@@ -677,18 +677,18 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
 
   // canopy roughness blend (canopy_fluxes_impl.hh:141-147)
-  r.elai = S->elai[c];
+  r.elai = FW(elai, S->elai[c]);
   PUT(elai)
-  r.esai = S->esai[c];
+  r.esai = FW(esai, S->esai[c]);
   PUT(esai)
-  r.z0mg = S->z0mg[c];
+  r.z0mg = FW(z0mg, S->z0mg[c]);
   PUT(z0mg)
   const double tlsai_crit = 2.0;
   const double lt = dmin(r.elai + r.esai, tlsai_crit);
   const double egvf = (1.0 - elmk_exp(-lt)) / (1.0 - elmk_exp(-tlsai_crit));
-  double displa = S->displa[c];
+  double displa = FW(displa, S->displa[c]);
   displa *= egvf;
-  double z0mv = S->z0mv[c];
+  double z0mv = FW(z0m, S->z0mv[c]);
   z0mv = elmk_exp(egvf * elmk_log(z0mv) + (1.0 - egvf) * elmk_log(r.z0mg));
   S->displa[c] = displa;
   S->z0mv[c] = z0mv;
@@ -700,48 +700,48 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   PUT(z0mv)
 
   // forcing, derived forcing (atm_physics_impl.hh:246-272) and the wrapper-level inputs of the iteration
-  r.forc_pbot = S->forc_pbot[c];
+  r.forc_pbot = FW(forc_pbot, S->forc_pbot[c]);
   PUT(forc_pbot)
-  r.forc_q = S->forc_qbot[c];
+  r.forc_q = FW(forc_q, S->forc_qbot[c]);
   PUT(forc_q)
-  r.forc_th = S->forc_thbot[c];
+  r.forc_th = FW(forc_th, S->forc_thbot[c]);
   PUT(forc_th)
-  r.forc_rho = derive_forc_rho(r.forc_pbot, r.forc_q, S->forc_tbot[c]);
+  r.forc_rho = derive_forc_rho(r.forc_pbot, r.forc_q, FW(forc_tbot, S->forc_tbot[c]));
   PUT(forc_rho)
-  r.thm = S->thm[c];
+  r.thm = FW(thm, S->thm[c]);
   PUT(thm)
-  r.thv = S->thv[c];
+  r.thv = FW(thv, S->thv[c]);
   PUT(thv)
-  r.qg = S->qg[c];
+  r.qg = FW(qg, S->qg[c]);
   PUT(qg)
-  r.t_grnd = S->t_grnd[c];
+  r.t_grnd = FW(t_grnd, S->t_grnd[c]);
   PUT(t_grnd)
-  r.hgt_u = S->forc_hgt_u_patch[c];
+  r.hgt_u = FW(hgt_u, S->forc_hgt_u_patch[c]);
   PUT(hgt_u)
-  r.hgt_t = S->forc_hgt_t_patch[c];
+  r.hgt_t = FW(hgt_t, S->forc_hgt_t_patch[c]);
   PUT(hgt_t)
-  r.hgt_q = S->forc_hgt_q_patch[c];
+  r.hgt_q = FW(hgt_q, S->forc_hgt_q_patch[c]);
   PUT(hgt_q)
   const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
   r.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
   PUT(ur)
-  r.htop = S->htop[c];
+  r.htop = FW(htop, S->htop[c]);
   PUT(htop)
   r.fwet = S->fwet[c];
   PUT(fwet)
   r.fdry = S->fdry[c];
   PUT(fdry)
-  r.laisun = S->laisun[c];
+  r.laisun = FW(laisun, S->laisun[c]);
   PUT(laisun)
-  r.laisha = S->laisha[c];
+  r.laisha = FW(laisha, S->laisha[c]);
   PUT(laisha)
-  r.soilbeta = S->soilbeta[c];
+  r.soilbeta = FW(soilbeta, S->soilbeta[c]);
   PUT(soilbeta)
-  r.sabv = S->sabv[c];
+  r.sabv = FW(sabv, S->sabv[c]);
   PUT(sabv)
-  r.h2ocan = S->h2ocan[c];
+  r.h2ocan = FW(h2ocan, S->h2ocan[c]);
   PUT(h2ocan)
-  const double emv = S->emv[c], emg = S->emg[c];
+  const double emv = FW(emv, S->emv[c]), emg = FW(emg, S->emg[c]);
   r.air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * S->forc_lwrad[c];  // :360-362
   r.bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
   PUT(air) PUT(bir)
@@ -751,19 +751,19 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   PUT(vcmaxcintsun)
   r.vcmaxcintsha = S->vcmaxcintsha[c];
   PUT(vcmaxcintsha)
-  const int nrad = S->nrad[c];
+  const int nrad = FW(nrad, S->nrad[c]);
   r.parsun = r.parsha = r.lai_sun_z = r.lai_sha_z = 0.0;
   if (nrad > 0) {
-    r.parsun = S->parsun_z[c];
-    r.parsha = S->parsha_z[c];
-    r.lai_sun_z = S->laisun_z[c];
-    r.lai_sha_z = S->laisha_z[c];
+    r.parsun = FW(parsun_z, S->parsun_z[c]);
+    r.parsha = FW(parsha_z, S->parsha_z[c]);
+    r.lai_sun_z = FW(laisun_z, S->laisun_z[c]);
+    r.lai_sha_z = FW(laisha_z, S->laisha_z[c]);
   }
   PUT(parsun) PUT(parsha) PUT(lai_sun_z) PUT(lai_sha_z)
   // loop-invariant sub-expression of the iteration body (:301-303)
   {
     const double snow_depth_c = 0.05;
-    const double fsno_dl = S->snow_depth[c] / snow_depth_c;
+    const double fsno_dl = FW(snow_depth, S->snow_depth[c]) / snow_depth_c;
     const double elai_dl = 0.5 * (1.0 - dmin(fsno_dl, 1.0));
     r.rdl_num = (1.0 - elmk_exp(-elai_dl));
     PUT(rdl_num)
@@ -783,9 +783,9 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   }
 
   // ground-emitted longwave (:366-367), loop-invariant
-  const double frac_sno = S->frac_sno[c], frac_h2osfc = S->frac_h2osfc[c];
+  const double frac_sno = FW(frac_sno, S->frac_sno[c]), frac_h2osfc = FW(frac_h2osfc, S->frac_h2osfc[c]);
   r.lw_grnd = (frac_sno * elmk_pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * elmk_pow(t_soi0, 4.0) +
-               frac_h2osfc * elmk_pow(S->t_h2osfc[c], 4.0));
+               frac_h2osfc * elmk_pow(FW(t_h2osfc, S->t_h2osfc[c]), 4.0));
   PUT(lw_grnd)
   S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
 
@@ -812,7 +812,25 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   const gptr<int32_t> irec = S->cf_irec + pos;
   irec[(int64_t)IREC_vtype * ld] = vtype;
   irec[(int64_t)IREC_nrad * ld] = nrad;
-  irec[(int64_t)IREC_fvn * ld] = S->frac_veg_nosno[c];
+  irec[(int64_t)IREC_fvn * ld] = FW(fvn, S->frac_veg_nosno[c]);
+}
+
+__global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
+{
+  elmk_math_lds_init<false>();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  if (L.lakpoi) {  // uniform: the wrapper does nothing on lake land units
+    if (blockIdx.x == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+    return;
+  }
+  const bool inside = c < S->ncols;
+  const int64_t pos = cf_queue_position(S, cf_class(S, L, c, inside));
+  if (!inside) return;
+  S->cf_pos[c] = (int32_t)pos;
+  ColFwd w;
+  cf_init_col<false>(S, c, ld, L, pos, w);
 }
 
 // =====================================================================================================
@@ -1322,7 +1340,12 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < CF_NCLS) CF_CLASS_COUNT(S, threadIdx.x) = 0u;  // for the next call's k_cf_count
   if (S->land.lakpoi || c >= S->ncols) return;
   const int32_t pos = S->cf_pos[c];
-  if (pos < 0) return;
+  if (pos < 0) {  // not vegetated: what is left of the bare branch (see cf_init_col)
+    S->cgrnd[c] = 0.0;
+    S->cgrnds[c] = 0.0;
+    S->cgrndl[c] = 0.0;
+    return;
+  }
   CfFin f;
   const gptr<const double> fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
 #define X(n) f.n = fin[FIN_##n * 8];
@@ -1391,6 +1414,123 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
     const int trips = (int)f.trips;
     const int decayed = (S->cf_niter[c] >> 16) - 1;
     S->cf_niter[c] = ((trips > decayed ? trips : decayed) << 16) | trips;
+  }
+}
+
+// =====================================================================================================
+// elmk_timestep7_fused: the seven wrappers of ELMInterface::advance (elm_kokkos_interface.cc:289-307) with the five
+// streaming ones between albedo and the leaf-temperature iteration as ONE pass per column.
+//
+//   k_fz_prep    frac_wet (it must precede albedo, which reads fwet); resets of the work lists of the step; the scheduling
+//                class of every column for the canopy_fluxes queue and the class counts (what k_cf_count does) - the class
+//                is computed from inputs of the step (frac_veg_nosno, coszen, the incident visible flux, last call's trip
+//                hint), because the queue slices must exist before the streaming pass places its records, and it is
+//                stored per column so that count and placement agree by construction (a class only orders the queue: any
+//                consistent choice gives the same results)
+//   albedo       k_alb_classify -> k_alb_snicar<1..5> -> k_alb_final, unchanged: it reads snl / h2osno / frac_sno as they
+//                are BEFORE canopy_hydrology, so it cannot join the pass
+//   k_fz_stream  canopy_hydrology -> surface_radiation -> canopy_temperature -> bareground_fluxes' streaming stage (cgrnd*
+//                reset, list of bare columns) -> canopy_fluxes' initialize_flux + queue record, in the reference's order, by
+//                the bodies the separate kernels use (elmk_stream.h, cf_init_col); each later body takes what an earlier
+//                one produced from registers: t_soisno[20] and some 45 scalars per column are neither re-read nor waited for
+//   k_bg_flux, k_cf_iterate, k_cf_finish   as in the unfused step
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
+{
+  elmk_math_lds_init<false>();  // (frac_wet: one pow per column)
+  __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];
+  for (int i = threadIdx.x; i < CF_COUNT_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < NLISTS && threadIdx.x != LIST_CF_QUEUE) {  // (the queue's own counters: cf_queue_position)
+    ELMK_LIST_COUNT(S, threadIdx.x) = 0u;
+    ELMK_LIST_HEAD(S, threadIdx.x) = 0u;
+  }
+  __syncthreads();
+  const Land L = S->land;
+  const int lane = threadIdx.x & 63;
+  const int64_t tile0 = (int64_t)blockIdx.x * CF_COUNT_TILES;
+#pragma unroll 4
+  for (int t = 0; t < CF_COUNT_TILES; t++) {  // (unrolled: the loads of several tiles are in flight together)
+    const int64_t c = (tile0 + t) * 256 + threadIdx.x;
+    const bool inside = c < S->ncols;
+    int cls = -1;
+    if (inside) {
+      frac_wet_col(S, c, L);
+      if (!L.lakpoi && !L.urbpoi && S->frac_veg_nosno[c] != 0) {
+        const bool day = S->coszen[c] > 0.0 && (S->forc_solad[c] > 0.0 || S->forc_solai[c] > 0.0);  // (band 0: visible)
+        cls = cf_class_of(day, S->cf_niter[c] >> 16);
+      }
+      S->cf_cls[c] = (int8_t)cls;
+    }
+#pragma unroll
+    for (int k = 0; k < CF_NCLS; k++) {
+      const unsigned long long m = __ballot(cls == k);
+      if (lane == 0 && m) atomicAdd(&s_cnt[t][k], (uint32_t)__popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CF_NCLS) {
+    const int k = threadIdx.x;
+    uint32_t n = 0u;
+    for (int t = 0; t < CF_COUNT_TILES; t++) n += s_cnt[t][k];
+    uint32_t base = n ? atomicAdd(ELMK_GENERIC(&CF_CLASS_COUNT(S, k)), n) : 0u;
+    for (int t = 0; t < CF_COUNT_TILES; t++) {
+      if (tile0 + t < S->cf_nblk) S->cf_blk[(int64_t)k * S->cf_nblk + tile0 + t] = base;
+      base += s_cnt[t][k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict__ S, double dtime)
+{
+  elmk_math_lds_init<false>();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  const bool inside = c < S->ncols;
+  // queue position of the canopy_fluxes record (every thread of the workgroup takes part in the barrier inside)
+  int64_t pos = -1;
+  if (!L.lakpoi) {
+    pos = cf_queue_position(S, inside ? (int)S->cf_cls[c] : -1);
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+  }
+  ColFwd w;
+  if (inside) {
+    canopy_hydrology_col<true>(S, c, ld, L, dtime, w);
+    surface_radiation_col<true>(S, c, ld, L, w);
+    canopy_temperature_col<true>(S, c, ld, L, w);
+  }
+  // bareground_fluxes, streaming stage (k_bg_main): compute_flux's unconditional cgrnd reset and the list of bare columns
+  if (!L.lakpoi) {
+    if (inside) {
+      S->cgrnd[c] = 0.0;
+      S->cgrnds[c] = 0.0;
+      S->cgrndl[c] = 0.0;
+    }
+    const bool bare = inside && !L.urbpoi && w.fvn == 0;
+    block_classify_append<1>(S->lists, ld, S->counters, LIST_BG, bare ? 0 : -1, (int32_t)c);
+    // canopy_fluxes up to the iteration
+    if (inside) {
+      S->cf_pos[c] = (int32_t)pos;
+      cf_init_col<true>(S, c, ld, L, pos, w);
+    }
+  }
+}
+
+void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st, const SideStreams* side, int stage)
+{
+  if (n <= 0) return;
+  const unsigned nblk = (unsigned)((n + 255) / 256);
+  switch (stage) {
+    case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S); break;
+    case 1: launch_albedo_snicar(S, n, st, side, false); break;
+    case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;
+    case 3: launch_bareground_list(S, n, st); break;
+    default: {
+      const unsigned groups = nblk < 512u ? nblk : 512u;
+      hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt);
+      hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt);
+    }
   }
 }
 

@@ -201,6 +201,12 @@ class ELMState:
         self._chk(self.lib.elmk_profile_timestep7(self.ctx, float(dt), int(nsteps), ms, C.byref(tot)), "profile_timestep7")
         return list(ms), tot.value
 
+    def profile_timestep7_fused(self, dt, nsteps):
+        ms = (C.c_float * len(KERNEL_NAMES_FUSED))()
+        tot = C.c_float()
+        self._chk(self.lib.elmk_profile_timestep7_fused(self.ctx, float(dt), int(nsteps), ms, C.byref(tot)), "profile_timestep7_fused")
+        return list(ms), tot.value
+
     def canopy_trip_counts(self):
         """Trips of the leaf-temperature iteration per column in the last canopy_fluxes call (0: not vegetated)."""
         out = np.zeros(self.ncols, dtype=np.int32)
@@ -249,6 +255,8 @@ KERNEL_NAMES = [
     "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
     "bareground_fluxes", "canopy_fluxes",
 ]
+# launch groups of elmk_timestep7_fused (include/elmk.h: elmk_profile_timestep7_fused)
+KERNEL_NAMES_FUSED = ["prep_frac_wet", "albedo_snicar", "fused_stream", "bareground_list", "canopy_iterate"]
 
 
 # ---- the L3 wrappers, named as in driver/kokkos/*_kokkos.hh ------------------------------------------
@@ -327,6 +335,12 @@ def kokkos_evaluate_conservation(S, dt, per_column=False):
     S._chk(S.lib.elmk_evaluate_conservation(S.ctx, float(dt), mms.ctypes.data_as(C.c_void_p),
                                             cols.ctypes.data_as(C.c_void_p) if per_column else None), "evaluate_conservation")
     return (mms, np.ascontiguousarray(cols.T)) if per_column else mms
+
+
+def timestep7_fused(S, dt):
+    """The same seven calls with the streaming wrappers between albedo and the leaf-temperature iteration fused into one
+    pass per column (elmk_timestep7_fused); bit-identical results."""
+    S._chk(S.lib.elmk_timestep7_fused(S.ctx, float(dt)), "timestep7_fused")
 
 
 def timestep7(S, dt):

@@ -25,7 +25,7 @@
  *   kokkos_canopy_temperature(S)    canopy_temperature_kokkos.hh      elmk_canopy_temperature
  *   kokkos_bareground_fluxes(S)     bareground_fluxes_kokkos.hh       elmk_bareground_fluxes
  *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
- *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7
+ *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7, elmk_timestep7_fused
  *   get_forcing(S, dt, date)        atm_forcing_kokkos.cc:47-75       elmk_get_forcing
  *   update_phenology: ComputePhenology  phenology_kokkos.cc:59-62     elmk_phenology
  *   kokkos_init_timestep's kernel   init_timestep_kokkos.cc:55-75     elmk_init_timestep
@@ -191,6 +191,13 @@ int elmk_canopy_temperature(elmk_ctx *ctx);
 int elmk_bareground_fluxes(elmk_ctx *ctx);
 int elmk_canopy_fluxes(elmk_ctx *ctx, double dt);
 int elmk_timestep7(elmk_ctx *ctx, double dt);
+/* The same seven calls (elm_kokkos_interface.cc:289-307) with the five streaming wrappers between albedo and the
+ * leaf-temperature iteration - canopy_hydrology, surface_radiation, canopy_temperature, the streaming stage of
+ * bareground_fluxes and canopy_fluxes' initialize_flux - fused into ONE pass per column: every state element the step
+ * touches is read once and written once (3 405 B per column-step instead of 5 281; BASELINE.json
+ * config 5's launch structure, fp64 state).  Results are bit-identical to elmk_timestep7 in every field.  elmk_set_graph
+ * applies to it as well. */
+int elmk_timestep7_fused(elmk_ctx *ctx, double dt);
 /* next in ELMInterface::advance (elm_kokkos_interface.cc:310): kokkos_soil_temperature(S, dt),
  * soil_temperature_kokkos.cc:6-278 - thermal properties, the 21-row pentadiagonal temperature system of
  * snow / standing surface water / soil, its solve, phase change, ground temperature */
@@ -233,6 +240,10 @@ int elmk_clear_errors(elmk_ctx *ctx);
  * time of one whole timestep (first event to last).  If a snapshot exists (elmk_snapshot_fields) it is
  * restored before every step, outside the event brackets, so each profiled step does the same work. */
 int elmk_profile_timestep7(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_kernel, float *ms_total);
+/* the same for elmk_timestep7_fused: ms_per_stage[5] = frac_wet + list resets + queue class count (k_fz_prep);
+ * albedo_snicar; the fused streaming pass (k_fz_stream); the bare-ground flux list; the leaf-temperature iteration +
+ * compute_flux (k_cf_iterate, k_cf_finish) */
+int elmk_profile_timestep7_fused(elmk_ctx *ctx, double dt, int nsteps, float *ms_per_stage, float *ms_total);
 /* the same for one wrapper: mean device time over nsteps launches, HIP events on the context's stream, the snapshot (if
  * any) restored before every launch outside the event brackets */
 typedef enum {

@@ -392,6 +392,58 @@ def test_graph_replay_is_the_same_step():
     B.close()
 
 
+def _same_bits(A, B, what):
+    for k in A.fields:
+        a, b = A[k], B[k]
+        same = np.array_equal(a, b, equal_nan=True) if a.dtype.kind != "f" else bool(
+            ((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all())
+        assert same, (what, k)
+
+
+@pytest.mark.parametrize("tier,n,seed", [("A", 4700, 91), ("B", 12000, 92), ("B", 1, 93), ("B", 63, 94), ("B", 257, 95), ("B", 1001, 96)])
+def test_fused_timestep_is_the_same_step(tier, n, seed):
+    """elmk_timestep7_fused (BASELINE config 5's launch structure: the five streaming wrappers between albedo and the
+    leaf-temperature iteration as one pass per column) against elmk_timestep7 on the same state and against the oracle:
+    bit-identical in EVERY field (state, error flags, trip counts) over three chained steps, ragged sizes included."""
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier=tier, seed=seed)
+    U = H.device_state(cols, scal, soil)
+    Fz = H.device_state(cols, scal, soil)
+    S = H.oracle_state(cols, scal, soil)
+    for step in range(3):
+        st.timestep7(U, DT)
+        st.timestep7_fused(Fz, DT)
+        S.timestep7(DT)
+        _same_bits(U, Fz, f"fused vs unfused, {tier}/{n}/step {step}")
+        _check(Fz, S, f"fused vs oracle, {tier}/{n}/step {step}", bitwise=True)
+        assert np.array_equal(U.canopy_trip_counts(), Fz.canopy_trip_counts())
+    U.close()
+    Fz.close()
+
+
+def test_fused_timestep_other_land_units_and_graph():
+    """The fused step on the land units that take the short branches (wetland, land ice, lake, urban), mixed with unfused
+    steps on the same context (the two launch structures share the queue scratch), and replayed as a HIP graph."""
+    for land in (dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0), dict(ltype=3, ctype=0, vtype=0, urbpoi=0, lakpoi=0),
+                 dict(ltype=5, ctype=0, vtype=0, urbpoi=0, lakpoi=1), dict(ltype=7, ctype=71, vtype=0, urbpoi=1, lakpoi=0)):
+        D, S = _pair(2000, "B", 21, land)
+        st.timestep7_fused(D, DT)
+        S.timestep7(DT)
+        _check(D, S, f"fused, land {land}", bitwise=True)
+        D.close()
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, 5000, tier="B", seed=97)
+    A = H.device_state(cols, scal, soil)
+    B = H.device_state(cols, scal, soil)
+    B.set_graph(True)
+    for i, dt in enumerate((DT, DT, 900.0, DT)):
+        (st.timestep7_fused if i % 2 == 0 else st.timestep7)(A, dt)  # alternate the two launch structures on A
+        st.timestep7_fused(B, dt)                                    # fused, replayed as a graph, on B
+        _same_bits(A, B, f"mixed / graph step {i}")
+    A.close()
+    B.close()
+
+
 def test_get_forcing_and_phenology():
     """The per-column functors kokkos_init_timestep runs first - get_forcing's eight ComputeAtmForcing_* functors (specific-
     and relative-humidity streams) and ComputePhenology - on records / months on both sides of every clamp: every field

@@ -45,6 +45,8 @@ SIGNATURES = {
     "elmk_canopy_temperature": (C.c_int, [_P]),
     "elmk_bareground_fluxes": (C.c_int, [_P]),
     "elmk_canopy_fluxes": (C.c_int, [_P, C.c_double]),
+    "elmk_canopy_fluxes_given": (C.c_int, [_P, C.c_double, _P, _P, _P]),
+    "elmk_bareground_fluxes_given": (C.c_int, [_P, _P]),
     "elmk_timestep7": (C.c_int, [_P, C.c_double]),
     "elmk_timestep7_fused": (C.c_int, [_P, C.c_double]),
     "elmk_profile_timestep7_fused": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -220,10 +220,11 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t pos_bytes = align_up((size_t)ctx->ld * 4, 256);
   const size_t blk_bytes = align_up((size_t)CF_NCLS * (size_t)cf_nblk * 4, 256);
   const size_t cls_bytes = align_up((size_t)ctx->ld, 256);
+  const size_t given_bytes = align_up((size_t)3 * (size_t)ctx->ld * 8, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
   const size_t stw_bytes = align_up((size_t)(40 + 42) * (size_t)ctx->ld * 8, 256);  // soil_temperature: thk, cv of the 20 levels; A, Z of the 21 rows
   const size_t cons_bytes = align_up((size_t)8 * (size_t)ctx->ld * 8 + (size_t)8 * ELMK_CONS_NPART * 3 * 8 + 8 * 3 * 8, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + cls_bytes + snow_bytes + stw_bytes + cons_bytes;
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + cls_bytes + given_bytes + snow_bytes + stw_bytes + cons_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -264,6 +265,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     q += blk_bytes;
     h.cf_cls = (gptr<int8_t>)q;
     q += cls_bytes;
+    h.cf_given = (gptr<double>)q;
+    q += given_bytes;
     h.alb_snow = (gptr<double>)q;
     q += snow_bytes;
     h.st_work = (gptr<double>)q;
@@ -638,6 +641,44 @@ int elmk_canopy_fluxes(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
   launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+// L2-level entries: the forcing-derived scalars handed in, as the reference's unit tests call the physics
+// (test/test_CanFlux.cc:285-340, test/test_BGFlux.cc:200-260) instead of the wrapper's derive_forc_* (atm_physics_impl.hh:246-272)
+namespace {
+int stage_given(elmk_ctx* ctx, const double* rho, const double* po2, const double* pco2, int* mask)
+{
+  const double* src[3] = {rho, po2, pco2};
+  *mask = 0;
+  for (int k = 0; k < 3; k++) {
+    if (!src[k] || ctx->ncols == 0) continue;
+    HIPCHK(hipMemcpyAsync(ELMK_GENERIC(ctx->h.cf_given) + (size_t)k * ctx->ld, src[k], (size_t)ctx->ncols * 8, hipMemcpyHostToDevice,
+                          ctx->stream));
+    *mask |= 1 << k;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // the sources are caller-owned pageable host arrays
+  return ELMK_OK;
+}
+}  // namespace
+
+int elmk_canopy_fluxes_given(elmk_ctx* ctx, double dt, const double* forc_rho, const double* forc_po2, const double* forc_pco2)
+{
+  PHYSICS_PROLOGUE();
+  int mask = 0;
+  if (int rc = stage_given(ctx, forc_rho, forc_po2, forc_pco2, &mask)) return rc;
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream, mask);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_bareground_fluxes_given(elmk_ctx* ctx, const double* forc_rho)
+{
+  PHYSICS_PROLOGUE();
+  int mask = 0;
+  if (int rc = stage_given(ctx, forc_rho, nullptr, nullptr, &mask)) return rc;
+  launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream, mask);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }

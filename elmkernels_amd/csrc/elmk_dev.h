@@ -125,7 +125,7 @@ enum : int {
 
 // canopy_fluxes queue records (k_canopy_fluxes.hip): per queue position, SoA [k][position] with stride ld
 constexpr int CF_NCLS = 12;    // scheduling classes: 6 bins of the previous call's trip count x (day, night)
-constexpr int CF_REC_N = 44;   // doubles a column carries into the iteration kernel
+constexpr int CF_REC_N = 46;   // doubles a column carries into the iteration kernel
 constexpr int CF_IREC_N = 3;   // int32: vtype, nrad, frac_veg_nosno
 constexpr int CF_FIN_N = 24;   // doubles the iteration kernel hands to the finishing kernel
 
@@ -194,6 +194,7 @@ struct DevState {
   gptr<double> cf_fin;      // CF_FIN_N x ld: converged iteration state, by queue position
   gptr<int32_t> cf_irec;    // CF_IREC_N x ld
   gptr<int32_t> cf_pos;     // queue position of each column (-1: not vegetated)
+  gptr<double> cf_given;    // 3 x ld: forc_rho, forc_po2, forc_pco2 handed in by the L2-level entries (elmk_*_given), by column
   gptr<int8_t> cf_cls;      // scheduling class of each column as k_fz_prep counted it (fused step)
   gptr<uint32_t> cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
   int64_t cf_nblk;     // workgroups of 256 columns

@@ -26,8 +26,9 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
 void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);
-void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st);
-void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
+// given (bit 0 forc_rho, bit 1 forc_po2, bit 2 forc_pco2): the L2-level entries elmk_*_given take these from DevState::cf_given
+void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int given = 0);
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given = 0);
 // elmk_timestep7_fused: the same seven wrappers as five launch groups (k_canopy_fluxes.hip):
 //   0 k_fz_prep (frac_wet, list resets, canopy_fluxes class count)   1 albedo_snicar   2 k_fz_stream (canopy_hydrology ->
 //   surface_radiation -> canopy_temperature -> bare-ground list -> canopy_fluxes initialize_flux, one pass per column)

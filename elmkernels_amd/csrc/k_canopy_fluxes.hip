@@ -462,7 +462,8 @@ constexpr int CF_BLOCK_EXTRA = 24;  // queue positions a wave claims beyond what
   X(forc_pbot) X(forc_q) X(forc_th) X(forc_rho) X(thm) X(thv) X(elai) X(esai) X(qg) X(t_grnd) X(z0mg) X(z0mv)          \
   X(hgt_u) X(hgt_t) X(hgt_q) X(displa) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha) X(rdl_num) X(soilbeta)        \
   X(sabv) X(h2ocan) X(air) X(bir) X(cir) X(lw_grnd) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun) X(parsha) X(lai_sun_z)   \
-  X(lai_sha_z) X(t10) X(vcmaxc) X(jmaxc) X(tpuc) X(t_veg) X(btran) X(um) X(obu)
+  X(lai_sha_z) X(t10) X(vcmaxc) X(jmaxc) X(tpuc) X(t_veg) X(btran) X(um) X(obu)                                       \
+  X(forc_po2) X(forc_pco2) /* only written and read by the L2-level entry elmk_canopy_fluxes_given */
 // doubles of a finish record (k_cf_iterate -> k_cf_finish)
 #define CF_FIN_FIELDS(X)                                                                                               \
   X(t_veg) X(btran) X(qflx_tran_veg) X(qflx_evap_veg) X(eflx_sh_veg) X(wtg) X(wtl0) X(wta0) X(wtal) X(wtgq) X(wtalq)   \
@@ -608,9 +609,11 @@ __device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict_
 // canopy_fluxes for one column up to the iteration: the bare branch, or initialize_flux (canopy_fluxes_impl.hh:95-184) and the
 // queue record.  One source for k_cf_init (inputs from the state) and the fused streaming stage (FUSED: the values the
 // earlier bodies of the same pass produced come through ColFwd).  pos: the column's queue position (-1: not vegetated).
+// given: bit 0 / 1 / 2 = forc_rho / forc_po2 / forc_pco2 come from S->cf_given (elmk_canopy_fluxes_given) instead of being
+// derived from the forcing as the wrapper does (canopy_fluxes_kokkos.cc:47-49)
 template <bool FUSED>
 __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                            const int64_t pos, const ColFwd& w)
+                                            const int64_t pos, const ColFwd& w, const int given = 0)
 {
   const bool inside = true, veg = pos >= 0;
   if (inside && !veg) {
@@ -707,7 +710,13 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   r.forc_th = FW(forc_th, S->forc_thbot[c]);
   PUT(forc_th)
   r.forc_rho = derive_forc_rho(r.forc_pbot, r.forc_q, FW(forc_tbot, S->forc_tbot[c]));
+  if (given & 1) r.forc_rho = S->cf_given[c];
   PUT(forc_rho)
+  if (given & 6) {
+    r.forc_po2 = (given & 2) ? S->cf_given[ld + c] : derive_forc_po2(r.forc_pbot);
+    r.forc_pco2 = (given & 4) ? S->cf_given[2 * ld + c] : derive_forc_pco2(r.forc_pbot);
+    PUT(forc_po2) PUT(forc_pco2)
+  }
   r.thm = FW(thm, S->thm[c]);
   PUT(thm)
   r.thv = FW(thv, S->thv[c]);
@@ -815,7 +824,7 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   irec[(int64_t)IREC_fvn * ld] = FW(fvn, S->frac_veg_nosno[c]);
 }
 
-__global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
+__global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S, const int given)
 {
   elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S)
   if (!inside) return;
   S->cf_pos[c] = (int32_t)pos;
   ColFwd w;
-  cf_init_col<false>(S, c, ld, L, pos, w);
+  cf_init_col<false>(S, c, ld, L, pos, w, given);
 }
 
 // =====================================================================================================
@@ -879,7 +888,7 @@ CF_LDS_FIELDS(X)
 #define C(n) cf_get_##n(R, s_col, tid)
 #define CSET(n, v) cf_set_##n(R, s_col, tid, (v))
 
-__global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevState* __restrict__ S, double dtime)
+__global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevState* __restrict__ S, double dtime, const int given)
 {
   elmk_math_lds_init<true>();
   __shared__ CfLds s_col[CF_NLDS];
@@ -1018,7 +1027,8 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
         CSET(tc10, dmin(dmax((t10 - TFRZ), 11.0), 35.0));
         CSET(cf, pbot / (RGAS * 1.0e-3 * thm) * 1.e06);
         const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
-        CSET(cp25, 0.5 * derive_forc_po2(pbot) / sco);
+        const double po2 = (given & 6) ? rec[REC_forc_po2 * 8] : derive_forc_po2(pbot);
+        CSET(cp25, 0.5 * po2 / sco);
       }
       // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
       btran = LD(btran);
@@ -1130,7 +1140,12 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
         J.theta_cj = PR[PFT_theta_cj];
         J.bbbopt = PR[PFT_bbbopt];
         J.mbbopt = PR[PFT_mbbopt];
-        const double forc_po2 = derive_forc_po2(C(forc_pbot)), forc_pco2 = derive_forc_pco2(C(forc_pbot));
+        double forc_po2 = derive_forc_po2(C(forc_pbot)), forc_pco2 = derive_forc_pco2(C(forc_pbot));
+        if (given & 6) {  // (L2-level entry only: the column's own values, kept in its queue record)
+          const gptr<const double> grec = S->cf_rec + CF_REC_BASE(pos);
+          forc_po2 = grec[REC_forc_po2 * 8];
+          forc_pco2 = grec[REC_forc_pco2 * 8];
+        }
         PR_T(2)
         rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
                                 C(lai_sun_z), err);
@@ -1332,7 +1347,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
 // k_cf_finish - one thread per column, coalesced: compute_flux (canopy_fluxes_impl.hh:456-540) from the converged
 // iteration state, the 2 m profiles of the last trip (friction_velocity_temp2m / _humidity2m, :239-240), state writes.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ S, double dtime)
+__global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ S, double dtime, const int given)
 {
   elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1358,7 +1373,8 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   S->qflx_evap_veg[c] = f.qflx_evap_veg;
   S->eflx_sh_veg[c] = f.eflx_sh_veg;
   const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c];
-  const double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
+  double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
+  if (given & 1) forc_rho = S->cf_given[c];
   const double thm = S->thm[c], t_grnd = S->t_grnd[c];
   const int snl = S->snl[c];
   const double t_soi0 = LV(t_soisno, NLEVSNO);
@@ -1528,23 +1544,23 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
     case 3: launch_bareground_list(S, n, st); break;
     default: {
       const unsigned groups = nblk < 512u ? nblk : 512u;
-      hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt);
-      hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt);
+      hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, 0);
+      hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt, 0);
     }
   }
 }
 
-void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st)
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given)
 {
   if (n <= 0) return;
   const unsigned nblk = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cf_count, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S);
-  hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S, given);
   // persistent: two waves per SIMD are resident at this kernel's register and LDS footprint (2 workgroups per CU, 512 in
   // all); workgroups that start later find the queue empty
   unsigned groups = nblk < 512u ? nblk : 512u;
-  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt);
-  hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt);
+  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, given);
+  hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt, given);
 }
 
 }  // namespace elmk

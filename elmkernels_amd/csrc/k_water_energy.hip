@@ -86,7 +86,7 @@ __global__ void k_bg_reset(const DevState* __restrict__ S)
 }
 
 // stage 2 (bare columns only, from the queue): the Monin-Obukhov iteration and the fluxes
-__global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
+__global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S, const int given)
 {
   const int64_t ld = S->ld;
   const uint32_t count = ELMK_LIST_COUNT(S, LIST_BG);
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S)
   const int64_t c = list[q];
 
   const double forc_pbot = S->forc_pbot[c], forc_q = S->forc_qbot[c], forc_th = S->forc_thbot[c];
-  const double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
+  double forc_rho = derive_forc_rho(forc_pbot, forc_q, S->forc_tbot[c]);
+  if (given & 1) forc_rho = S->cf_given[c];  // elmk_bareground_fluxes_given
   const double thm = S->thm[c], thv = S->thv[c], t_grnd = S->t_grnd[c], qg = S->qg[c], z0mg = S->z0mg[c];
   const double hgt_u = S->forc_hgt_u_patch[c], hgt_t = S->forc_hgt_t_patch[c], hgt_q = S->forc_hgt_q_patch[c];
   const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
@@ -203,16 +204,16 @@ void launch_bareground_list(const DevState* S, int64_t n, hipStream_t st)
 {
   if (n <= 0) return;
   const unsigned full = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, 0);
 }
 
-void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st)
+void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int given)
 {
   if (n <= 0) return;
   const unsigned full = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_bg_reset, dim3(1), dim3(64), 0, st, S);
   hipLaunchKernelGGL(k_bg_main, dim3(full), dim3(256), 0, st, S);
-  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, given);
 }
 
 }  // namespace elmk

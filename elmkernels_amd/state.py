@@ -288,6 +288,25 @@ def kokkos_canopy_fluxes(S, dt):
     S._chk(S.lib.elmk_canopy_fluxes(S.ctx, float(dt)), "canopy_fluxes")
 
 
+def _opt(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def canopy_fluxes_given(S, dt, forc_rho=None, forc_po2=None, forc_pco2=None):
+    """L2-level canopy_fluxes: forcing-derived scalars handed in (test/test_CanFlux.cc) instead of derived by the wrapper."""
+    a = [_opt(x) for x in (forc_rho, forc_po2, forc_pco2)]
+    assert all(x is None or x.shape == (S.ncols,) for x in a)
+    S._chk(S.lib.elmk_canopy_fluxes_given(S.ctx, float(dt), *[None if x is None else x.ctypes.data_as(C.c_void_p) for x in a]),
+           "canopy_fluxes_given")
+
+
+def bareground_fluxes_given(S, forc_rho):
+    """L2-level bareground_fluxes with ELM's own air density (test/test_BGFlux.cc)."""
+    a = _opt(forc_rho)
+    assert a.shape == (S.ncols,)
+    S._chk(S.lib.elmk_bareground_fluxes_given(S.ctx, a.ctypes.data_as(C.c_void_p)), "bareground_fluxes_given")
+
+
 def kokkos_soil_temperature(S, dt):
     """Next in ELMInterface::advance after the seven (elm_kokkos_interface.cc:310; soil_temperature_kokkos.cc:6-278)."""
     S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")

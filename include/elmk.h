@@ -190,6 +190,12 @@ int elmk_surface_radiation(elmk_ctx *ctx);
 int elmk_canopy_temperature(elmk_ctx *ctx);
 int elmk_bareground_fluxes(elmk_ctx *ctx);
 int elmk_canopy_fluxes(elmk_ctx *ctx, double dt);
+/* L2-level forms of the two flux wrappers: the forcing-derived scalars air density / O2 / CO2 partial pressure (per column,
+ * host arrays of ncols doubles; NULL = derive it as the wrapper does, canopy_fluxes_kokkos.cc:47-49 /
+ * bareground_fluxes_kokkos.cc:31) handed in, which is how the reference's unit tests drive the physics with the values ELM
+ * itself used (test/test_CanFlux.cc, test/test_BGFlux.cc).  Everything else as elmk_canopy_fluxes / elmk_bareground_fluxes. */
+int elmk_canopy_fluxes_given(elmk_ctx *ctx, double dt, const double *forc_rho, const double *forc_po2, const double *forc_pco2);
+int elmk_bareground_fluxes_given(elmk_ctx *ctx, const double *forc_rho);
 int elmk_timestep7(elmk_ctx *ctx, double dt);
 /* The same seven calls (elm_kokkos_interface.cc:289-307) with the five streaming wrappers between albedo and the
  * leaf-temperature iteration - canopy_hydrology, surface_radiation, canopy_temperature, the streaming stage of

@@ -162,6 +162,98 @@ def test_fixture_steps_on_device():
         D.close()
 
 
+def _fixture_device_state(module, rows, pft, optics, **scalars):
+    d = F.load(module)
+    D = st.ELMState(len(rows))
+    D.set_pft(pft)
+    D.set_snicar(optics)
+    D.set_land(**F.TEST_LAND)
+    if scalars:
+        D.set_scalars(**scalars)
+    nlev = {k: v[1] for k, v in D.fields.items()}
+    fin, oin = F.split(d, "in/", rows, nlev)
+    fout, _ = F.split(d, "out/", rows, nlev)
+    for k, v in fin.items():
+        D[k] = np.nan_to_num(v, nan=0.0) if D.fields[k][2] != np.float64 else v
+    D["vtype"] = np.full(len(rows), F.TEST_LAND["vtype"], np.int32)
+    D["veg_active"] = np.ones(len(rows), np.uint8)
+    return D, oin, fout
+
+
+def test_canopy_fluxes_fixture_on_device():
+    """The reference's CanopyFluxes fixture (test/test_CanFlux.cc, test/data/CanopyFluxes_{IN,OUT}.txt, 97 steps, 50 by day
+    and 47 by night) through the HIP kernels: driven as the reference's test drives the physics - ELM's own forc_rho /
+    forc_po2 / forc_pco2 handed in (elmk_canopy_fluxes_given; ELM ran 397.84 ppm CO2, the wrapper hard-wires 355) and the
+    step's dayl / max_dayl (a state scalar: the steps are grouped by it).  Same bar as the oracle holds against this
+    fixture and as the compiled reference itself shows (73 of 8 633 values beyond 1e-15, worst
+    3.5e-10): <= 120 values beyond 1e-15, all < 1e-9; and bit-identical to the oracle on the same steps."""
+    from oracle import oracle as O
+
+    pft, optics = synth.load_params()
+    d = F.load("CanopyFluxes")
+    rows = F.select_steps(d, "CanopyFluxes")
+    dayl, mdl = d["in/dayl"][rows, 0], d["in/max_dayl"][rows, 0]
+    groups = {}
+    for i, key in enumerate(zip(dayl.tolist(), mdl.tolist())):
+        groups.setdefault(key, []).append(i)
+    assert 1 <= len(groups) <= 8
+    total = nloose = 0
+    worst = 0.0
+    nday = 0
+    for (dl, ml), idx in groups.items():
+        sub = rows[np.array(idx)]
+        D, oin, fout = _fixture_device_state("CanopyFluxes", sub, pft, optics, dayl=dl, max_dayl=ml)
+        st.canopy_fluxes_given(D, F.TEST_DTIME, oin["forc_rho"][:, 0], oin["forc_po2"][:, 0], oin["forc_pco2"][:, 0])
+        # the oracle on the same columns, same entry
+        S = O.OracleState(len(sub))
+        S.load_params(pft, optics)
+        S.set_scalars(**F.TEST_LAND, dayl=dl, max_dayl=ml)
+        fin, _ = F.split(d, "in/", sub, S.nlev)
+        F.fill_state(S, fin)
+        S["vtype"][:] = F.TEST_LAND["vtype"]
+        S.canopy_fluxes_given(F.TEST_DTIME, oin["forc_rho"][:, 0], oin["forc_po2"][:, 0], oin["forc_pco2"][:, 0])
+        for name, exp in fout.items():
+            got = D[name].reshape(len(sub), -1).astype(np.float64)
+            ok = F.almost_equal(got, exp) | np.isnan(exp)
+            total += ok.size
+            nloose += int((~ok).sum())
+            if not ok.all():
+                worst = max(worst, float(np.where(ok, 0.0, F.rel_err(got, exp, floor=1e-18)).max()))
+            ref = np.ascontiguousarray(S[name].reshape(len(sub), -1))
+            if ref.dtype.kind == "f":
+                assert ((got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))).all(), name
+        flags, _ = D.error_summary()
+        assert (flags & 0x7FF) == 0
+        trips = D.canopy_trip_counts()
+        assert trips.min() >= 3 and trips.max() <= 41
+        nday += int((d["in/parsun_z"][sub].reshape(len(sub), -1)[:, 0] > 0).sum())
+        D.close()
+    assert total >= 8633 and nloose <= 120 and worst < 1e-9, (total, nloose, worst)
+    assert 0 < nday < len(rows)  # both the day branch (root finds) and the night branch ran
+
+
+def test_bareground_fluxes_fixture_on_device():
+    """The reference's BareGroundFluxes fixture through the HIP kernels, as test/test_BGFlux.cc drives it: frac_veg_nosno
+    hard-wired to 0 (:219: the fixture itself never takes the bare branch) and ELM's own forc_rho handed in
+    (elmk_bareground_fluxes_given): every value within the reference's own 1e-15 of the _OUT records."""
+    pft, optics = synth.load_params()
+    d = F.load("BareGroundFluxes")
+    rows = F.select_steps(d, "BareGroundFluxes")
+    D, oin, fout = _fixture_device_state("BareGroundFluxes", rows, pft, optics)
+    D["frac_veg_nosno"] = np.zeros(len(rows), np.int32)
+    st.bareground_fluxes_given(D, oin["forc_rho"][:, 0])
+    total = 0
+    for name, exp in fout.items():
+        if name == "frac_veg_nosno":
+            continue
+        got = D[name].reshape(len(rows), -1).astype(np.float64)
+        ok = F.almost_equal(got, exp) | np.isnan(exp)
+        total += ok.size
+        assert ok.all(), (name, float(np.where(ok, 0.0, F.rel_err(got, exp)).max()))
+    assert total >= 2000
+    D.close()
+
+
 def test_tiling_invariance_at_scale():
     """Size-independent property at a BASELINE-scale N: tiling without perturbation must reproduce the base block's
     results in every tile, bit for bit (columns are independent; no cross-column state)."""

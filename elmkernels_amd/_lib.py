@@ -51,6 +51,8 @@ SIGNATURES = {
     "elmk_timestep7_fused": (C.c_int, [_P, C.c_double]),
     "elmk_profile_timestep7_fused": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_soil_temperature": (C.c_int, [_P, C.c_double]),
+    "elmk_snow_hydrology": (C.c_int, [_P, C.c_double]),
+    "elmk_set_snow_age_tables": (C.c_int, [_P, _P, _P, _P]),
     "elmk_surface_fluxes": (C.c_int, [_P, C.c_double]),
     "elmk_init_timestep": (C.c_int, [_P]),
     "elmk_set_graph": (C.c_int, [_P, C.c_int]),

@@ -62,6 +62,7 @@ struct elmk_ctx {
   size_t arena_bytes = 0;
   void* fptr[ELMK_NUM_FIELDS] = {};
   double* snicar = nullptr;
+  double* snowage = nullptr;  // SnwRdsTable (elmk_set_snow_age_tables)
   char* scratch = nullptr;  // work arrays + work lists + queue counters of the compacted kernels
   size_t scratch_bytes = 0;
   char* staging = nullptr;  // device staging for layout conversion
@@ -207,6 +208,10 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->snicar, 0, SN_TOTAL * sizeof(double), ctx->stream), "hipMemset(snicar)"))
     return fail(ELMK_E_HIP);
+  if (hip_fail(ctx, hipMalloc((void**)&ctx->snowage, 3 * ELMK_SNOWAGE_N * sizeof(double)), "hipMalloc(snowage)"))
+    return fail(ELMK_E_NOMEM);
+  if (hip_fail(ctx, hipMemsetAsync(ctx->snowage, 0, 3 * ELMK_SNOWAGE_N * sizeof(double), ctx->stream), "hipMemset(snowage)"))
+    return fail(ELMK_E_HIP);
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
   const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
   const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
@@ -247,6 +252,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.dewmx = 0.1;
   h.oldfflag = 1;
   h.snicar = (gptr<const double>)ctx->snicar;
+  h.snowage = (gptr<const double>)ctx->snowage;
   h.wk = (gptr<double>)ctx->scratch;
   h.lists = (gptr<int32_t>)(ctx->scratch + wk_bytes);
   h.counters = (gptr<uint32_t>)(ctx->scratch + wk_bytes + list_bytes);
@@ -294,6 +300,7 @@ int elmk_destroy(elmk_ctx* ctx)
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->snicar) (void)hipFree(ctx->snicar);
+  if (ctx->snowage) (void)hipFree(ctx->snowage);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d) (void)hipFree(ctx->d);
   for (GraphSlot& g : ctx->graph)
@@ -349,7 +356,7 @@ int64_t elmk_ncols(const elmk_ctx* ctx) { return ctx ? ctx->ncols : -1; }
 int64_t elmk_level_stride(const elmk_ctx* ctx) { return ctx ? ctx->ld : -1; }
 int64_t elmk_device_bytes(const elmk_ctx* ctx)
 {
-  return ctx ? (int64_t)(ctx->arena_bytes + ctx->staging_bytes + ctx->scratch_bytes + SN_TOTAL * sizeof(double) + sizeof(DevState)) : -1;
+  return ctx ? (int64_t)(ctx->arena_bytes + ctx->staging_bytes + ctx->scratch_bytes + (SN_TOTAL + 3 * ELMK_SNOWAGE_N) * sizeof(double) + sizeof(DevState)) : -1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -588,6 +595,18 @@ int elmk_set_snicar(elmk_ctx* ctx, const elmk_snicar_tables* t)
   return ELMK_OK;
 }
 
+int elmk_set_snow_age_tables(elmk_ctx* ctx, const double* tau, const double* kappa, const double* drdt0)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (!tau || !kappa || !drdt0) return invalid(ctx, "elmk_set_snow_age_tables: null table");
+  const double* src[3] = {tau, kappa, drdt0};
+  for (int k = 0; k < 3; k++)
+    HIPCHK(hipMemcpyAsync(ctx->snowage + (size_t)k * ELMK_SNOWAGE_N, src[k], ELMK_SNOWAGE_N * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ELMK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // physics wrappers: one launch each, same order/arguments as driver/kokkos
 // ---------------------------------------------------------------------------------------------------
@@ -687,6 +706,14 @@ int elmk_soil_temperature(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
   launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_snow_hydrology(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  launch_snow_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }
@@ -903,6 +930,8 @@ void launch_one_wrapper(elmk_ctx* ctx, int wrapper, double dt)
     launch_stage7(ctx, wrapper, dt);
   else if (wrapper == ELMK_WRAPPER_SOIL_TEMPERATURE)
     launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
+  else if (wrapper == ELMK_WRAPPER_SNOW_HYDROLOGY)
+    launch_snow_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
   else
     launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
 }
@@ -912,7 +941,7 @@ int elmk_profile_wrapper(elmk_ctx* ctx, int wrapper, double dt, int nsteps, floa
 {
   PHYSICS_PROLOGUE();
   if (nsteps <= 0 || !ms_mean) return invalid(ctx, "elmk_profile_wrapper: bad arguments");
-  if (wrapper < 0 || wrapper > ELMK_WRAPPER_SURFACE_FLUXES) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
+  if (wrapper < 0 || wrapper > ELMK_WRAPPER_SNOW_HYDROLOGY) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
   EventList ev;
   HIPCHK(ev.create((size_t)nsteps * 2));
   for (int s = 0; s < nsteps; s++) {

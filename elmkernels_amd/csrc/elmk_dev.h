@@ -62,6 +62,7 @@ enum : int {
 constexpr int NLEVSNO = ELMK_NLEVSNO;
 constexpr int NLEVGRND = ELMK_NLEVGRND;
 constexpr int NLEVTOT = ELMK_NLEVTOT;
+constexpr int ELMK_SNOWAGE_N = 11 * 31 * 8;  // SnwRdsTable extents (snicar_data_impl.hh:42-47, snow_snicar.h:34-39)
 
 // Device pointers of the parameter block are GLOBAL-address-space pointers.  A plain C++ pointer loaded from a struct in
 // memory is a generic ("flat") pointer to the compiler: every access through it is a flat_load / flat_store, which may
@@ -182,6 +183,7 @@ struct DevState {
   double z0mr[ELMK_MXPFT], displar[ELMK_MXPFT];
   double albsat[ELMK_NSOILCOL][2], albdry[ELMK_NSOILCOL][2];
   gptr<const double> snicar;  // SN_TOTAL doubles
+  gptr<const double> snowage;  // 3 x ELMK_SNOWAGE_N: SnwRdsTable snowage_tau, snowage_kappa, snowage_drdt0 [11][31][8]
   // per-call scratch owned by the context (never part of the state contract):
   gptr<double> wk;          // WK_N work arrays, SoA [k][column] with the same level stride ld
   gptr<int32_t> lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)

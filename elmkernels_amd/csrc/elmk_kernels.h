@@ -38,6 +38,8 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
 void launch_bareground_list(const DevState* S, int64_t n, hipStream_t st);
 // next row after the seven: soil / snow column temperature
 void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st);
+// snow hydrology, aerosol masses, transpiration sink (k_snow_hydrology.hip)
+void launch_snow_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 // surface fluxes after the solve, conservation diagnostics reduced to (min, max, sum)
 constexpr int ELMK_CONS_NPART = 512;  // stage-1 partials per diagnostic
 void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);

@@ -180,6 +180,12 @@ class ELMState:
             setattr(t, name, a.ctypes.data)
         self._chk(self.lib.elmk_set_snicar(self.ctx, C.byref(t)), "set_snicar")
 
+    def set_snow_age_tables(self, tables):
+        """SnwRdsTable: tables [3, 11, 31, 8] = snowage_tau, snowage_kappa, snowage_drdt0."""
+        t = np.ascontiguousarray(tables, dtype=np.float64)
+        assert t.shape == (3, 11, 31, 8)
+        self._chk(self.lib.elmk_set_snow_age_tables(self.ctx, *[t[k].ctypes.data_as(C.c_void_p) for k in range(3)]), "set_snow_age_tables")
+
     # -- control ----------------------------------------------------------------------------------
     def sync(self):
         self._chk(self.lib.elmk_sync(self.ctx), "sync")
@@ -250,7 +256,7 @@ class ELMState:
 
 MATH_FNS = ["exp", "log", "log10", "atan", "sqrt", "tanh", "cos", "erf", "acos", "expm1", "div", "pow"]
 WRAPPER_NAMES = ["frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
-                 "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes"]
+                 "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes", "snow_hydrology"]
 KERNEL_NAMES = [
     "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
     "bareground_fluxes", "canopy_fluxes",
@@ -310,6 +316,11 @@ def bareground_fluxes_given(S, forc_rho):
 def kokkos_soil_temperature(S, dt):
     """Next in ELMInterface::advance after the seven (elm_kokkos_interface.cc:310; soil_temperature_kokkos.cc:6-278)."""
     S._chk(S.lib.elmk_soil_temperature(S.ctx, float(dt)), "soil_temperature")
+
+
+def kokkos_snow_hydrology(S, dt):
+    """snow_hydrology_kokkos.cc:23-188 (between soil_temperature and surface_fluxes in ELMInterface::advance, :313)."""
+    S._chk(S.lib.elmk_snow_hydrology(S.ctx, float(dt)), "snow_hydrology")
 
 
 def get_forcing(S, wt1, wt2, qbot_is_rh=False):

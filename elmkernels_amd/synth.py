@@ -238,7 +238,41 @@ def make_state(field_table, n, tier="A", seed=0x5EEDE1A0, perturb=True):
         cols["frac_veg_nosno_alb"] = cols["frac_veg_nosno"].copy()
     if "atm_tbot" in cols:
         cols.update(forcing_streams(cols, seed))
+    if "mss_bcphi" in cols:
+        cols.update(snow_aerosols(cols, seed))
     return cols, scal, soil
+
+
+def snow_aerosols(cols, seed):
+    """Inputs of kokkos_snow_hydrology no fixture carries: aerosol masses consistent with the concentrations SNICAR reads
+    (mss = cnc * layer water mass, what update_aerosol_mass_and_concen maintains), deposition rates of the eleven
+    AerosolFileInput streams (kg/m2/s), and the previous step's dew / sublimation / evaporation on the snow surface."""
+    n = cols["snl"].shape[0]
+    rng = np.random.default_rng(seed + 4099)
+    out = {}
+    mass = cols["h2osoi_ice"][:, :5] + cols["h2osoi_liq"][:, :5]
+    for a in ("bcphi", "bcpho", "dst1", "dst2", "dst3", "dst4"):
+        out["mss_" + a] = cols["cnc_" + a] * mass
+    for a in ("bcphi", "bcpho", "bcdep", "dst1_1", "dst1_2", "dst2_1", "dst2_2", "dst3_1", "dst3_2", "dst4_1", "dst4_2"):
+        out["aer_" + a] = 1e-12 * rng.random(n) * (rng.random(n) < 0.7)
+    snow = cols["h2osno"] > 0
+    out["qflx_sub_snow"] = np.where(snow & (rng.random(n) < 0.4), 2e-6 * rng.random(n), 0.0)
+    out["qflx_dew_snow"] = np.where(snow & (out["qflx_sub_snow"] == 0) & (rng.random(n) < 0.3), 1e-6 * rng.random(n), 0.0)
+    out["qflx_evap_grnd"] = np.where(rng.random(n) < 0.4, 3e-6 * rng.random(n), 0.0)
+    out["qflx_dew_grnd"] = np.where((out["qflx_evap_grnd"] == 0) & (rng.random(n) < 0.3), 1e-6 * rng.random(n), 0.0)
+    return out
+
+
+def snow_age_tables(seed=11):
+    """SnwRdsTable (snicar_data.h:75-84): snowage_tau / kappa / drdt0 [11, 31, 8].  The reference reads them from
+    snicar_drdt_bst_fit_60_c070416.nc, which is not in its repository: synthetic positive values of the right order of
+    magnitude (hours, unitless, um/hr), smooth in temperature / gradient / density."""
+    rng = np.random.default_rng(seed)
+    T, G, R = np.meshgrid(np.arange(11), np.arange(31), np.arange(8), indexing="ij")
+    tau = 50.0 + 30.0 * T + 5.0 * G + 10.0 * R + rng.random((11, 31, 8))
+    kappa = 1.2 + 0.05 * T + 0.02 * G + 0.01 * R + 0.01 * rng.random((11, 31, 8))
+    drdt0 = 0.5 + 0.3 * T + 0.1 * G + 0.02 * R + 0.01 * rng.random((11, 31, 8))
+    return np.stack([tau, kappa, drdt0])
 
 
 def forcing_streams(cols, seed):

@@ -30,6 +30,8 @@
  *   update_phenology: ComputePhenology  phenology_kokkos.cc:59-62     elmk_phenology
  *   kokkos_init_timestep's kernel   init_timestep_kokkos.cc:55-75     elmk_init_timestep
  *   kokkos_soil_temperature(S,dt)   soil_temperature_kokkos.hh        elmk_soil_temperature
+ *   kokkos_snow_hydrology(S,dt,t)   snow_hydrology_kokkos.hh          elmk_snow_hydrology
+ *   S.snw_rds_table (SnwRdsTable)   src/data/snicar_data.h:75-84      elmk_set_snow_age_tables
  *   kokkos_surface_fluxes(S,dt)     surface_fluxes_kokkos.hh          elmk_surface_fluxes
  *   kokkos_evaluate_conservation    conserved_quantity_kokkos.hh      elmk_evaluate_conservation
  *   throw / assert inside physics   (list: SURVEY.md section 5)       per-column flag word, elmk_error_summary
@@ -111,9 +113,21 @@ enum {
   ELMK_ERR_SNICAR_NEG_ABS = 1u << 8,    /* snow_snicar_impl.hh:618 */
   ELMK_ERR_SNICAR_ENERGY = 1u << 9,     /* snow_snicar_impl.hh:658 */
   ELMK_ERR_SNICAR_ALBEDO = 1u << 10,    /* snow_snicar_impl.hh:664 */
-  ELMK_WARN_PSN_BALL_BERRY = 1u << 11   /* photosynthesis_impl.hh:240 (std::cout warning, not fatal) */
+  ELMK_WARN_PSN_BALL_BERRY = 1u << 11,  /* photosynthesis_impl.hh:240 (std::cout warning, not fatal) */
+  /* elmk_snow_hydrology.  Two places where the reference reads outside an array, so that its own result is undefined; the
+   * column continues with the documented choice and the flag records that it was taken (not fatal):
+   *   snow_hydrology_impl.hh:388  snow_water reads vol_ice[i+i] (meant i+1) of a 5-element array; i <= 2 is in bounds and is
+   *                               reproduced literally, for i = 3 (index 6) vol_ice[i+1] is used;
+   *   snow_hydrology_impl.hh:871-885  combine_layers' shift loop copies element top-1 into top; with five snow layers that
+   *                               is element -1 of the level arrays: 0.0 is used (the element ends up above the pack and
+   *                               is reset by prune_snow_layers / the aerosol update / snow_aging).
+   * and the path's two throw sites (fatal): */
+  ELMK_WARN_SNOW_WATER_OOB = 1u << 12,
+  ELMK_WARN_SNOW_COMBINE_OOB = 1u << 13,
+  ELMK_ERR_SNOW_DIVIDE_RDS = 1u << 14,  /* snow_hydrology_impl.hh:1032, :1109, :1187, :1253 radius outside the Mie table */
+  ELMK_ERR_SNOW_AGE_DRFRESH = 1u << 15  /* snow_hydrology_impl.hh:152 dr_fresh < 0 */
 };
-#define ELMK_ERR_FATAL_MASK 0x7FFu
+#define ELMK_ERR_FATAL_MASK 0xC7FFu
 
 /* SNICAR lookup tables, names and extents of ELM::SnicarData (src/data/snicar_data.h:39-69); all row-major */
 typedef struct {
@@ -181,6 +195,9 @@ int elmk_set_scalars(elmk_ctx *ctx, double dewmx, int oldfflag, double dayl, dou
 int elmk_set_pft(elmk_ctx *ctx, const double *psn, const double *alb, const double *z0mr, const double *displar);
 int elmk_set_soilcolor(elmk_ctx *ctx, const double *albsat /*[20][2]*/, const double *albdry /*[20][2]*/);
 int elmk_set_snicar(elmk_ctx *ctx, const elmk_snicar_tables *t);
+/* SnwRdsTable (src/data/snicar_data.h:75-84): the snow-aging best-fit parameters snowage_tau [hour], snowage_kappa and
+ * snowage_drdt0 [um/hour], each [11][31][8] = [temperature][temperature gradient][density] index, row-major */
+int elmk_set_snow_age_tables(elmk_ctx *ctx, const double *tau, const double *kappa, const double *drdt0);
 
 /* ---- the physics wrappers (same names, order and arguments as driver/kokkos) ---------------- */
 int elmk_frac_wet(elmk_ctx *ctx);
@@ -208,6 +225,16 @@ int elmk_timestep7_fused(elmk_ctx *ctx, double dt);
  * soil_temperature_kokkos.cc:6-278 - thermal properties, the 21-row pentadiagonal temperature system of
  * snow / standing surface water / soil, its solve, phase change, ground temperature */
 int elmk_soil_temperature(elmk_ctx *ctx, double dt);
+/* kokkos_snow_hydrology(S, dt, time_plus_half_dt) (snow_hydrology_kokkos.cc:23-188; elm_kokkos_interface.cc:313, between
+ * soil_temperature and surface_fluxes; the date argument is unused by the reference's wrapper): snow_water,
+ * compute_aerosol_deposition, aerosol_phase_change, transpiration, snow_compaction, combine_layers, divide_layers,
+ * prune_snow_layers, update_aerosol_mass_and_concen, snow_aging - five launches in the reference, one pass per column here.
+ * Updates snl and the snow mesh (dz, zsoi, zisoi, t_soisno, h2osoi_ice/liq of the snow levels and of the top soil level),
+ * snw_rds, the aerosol masses mss_* and concentrations cnc_*, h2osno, snow_depth, frac_sno(_eff), int_snow, qflx_snow_melt,
+ * qflx_top_soil, qflx_sl_top_soil, qflx_snow2topsoi, mflx_*, qflx_rootsoi.  PARITY UNPINNED against the reference (it has
+ * no fixture for this path and its header does not build without netcdf); see ELMK_WARN_SNOW_* for the two places where
+ * the reference's own result is undefined. */
+int elmk_snow_hydrology(elmk_ctx *ctx, double dt);
 /* kokkos_surface_fluxes(S, dt) (surface_fluxes_kokkos.cc:5-107): flux corrections for the new ground temperature,
  * ground heat flux, total fluxes, dew / sublimation partition, outgoing longwave, soil energy balance */
 int elmk_surface_fluxes(elmk_ctx *ctx, double dt);
@@ -255,7 +282,7 @@ int elmk_profile_timestep7_fused(elmk_ctx *ctx, double dt, int nsteps, float *ms
 typedef enum {
   ELMK_WRAPPER_FRAC_WET = 0, ELMK_WRAPPER_ALBEDO_SNICAR, ELMK_WRAPPER_CANOPY_HYDROLOGY, ELMK_WRAPPER_SURFACE_RADIATION,
   ELMK_WRAPPER_CANOPY_TEMPERATURE, ELMK_WRAPPER_BAREGROUND_FLUXES, ELMK_WRAPPER_CANOPY_FLUXES,
-  ELMK_WRAPPER_SOIL_TEMPERATURE, ELMK_WRAPPER_SURFACE_FLUXES
+  ELMK_WRAPPER_SOIL_TEMPERATURE, ELMK_WRAPPER_SURFACE_FLUXES, ELMK_WRAPPER_SNOW_HYDROLOGY
 } elmk_wrapper;
 int elmk_profile_wrapper(elmk_ctx *ctx, int wrapper, double dt, int nsteps, float *ms_mean);
 /* Read back context-owned scratch (diagnostics; not part of the state contract).

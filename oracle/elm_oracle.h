@@ -40,7 +40,8 @@ enum {
   ELMO_SNO_NBR_AER = 8,
   ELMO_MXPFT = 25,
   ELMO_NSOILCOL = 20,
-  ELMO_MIE_N = 1471
+  ELMO_MIE_N = 1471,
+  ELMO_SNOWAGE_N = 11 * 31 * 8
 };
 
 /* per-column error flag bits: one per reference throw / assert site */
@@ -56,7 +57,13 @@ enum {
   ELMO_ERR_SNICAR_NEG_ABS = 1u << 8,      /* snow_snicar_impl.hh:618 */
   ELMO_ERR_SNICAR_ENERGY = 1u << 9,       /* snow_snicar_impl.hh:658 */
   ELMO_ERR_SNICAR_ALBEDO = 1u << 10,      /* snow_snicar_impl.hh:664 */
-  ELMO_WARN_PSN_BALL_BERRY = 1u << 11     /* photosynthesis_impl.hh:240 (std::cout warning) */
+  ELMO_WARN_PSN_BALL_BERRY = 1u << 11,    /* photosynthesis_impl.hh:240 (std::cout warning) */
+  /* snow hydrology (elmo_physics_g.c): two places where the reference reads outside an array (its result is undefined;
+   * the documented choice was taken) and its two throw sites */
+  ELMO_WARN_SNOW_WATER_OOB = 1u << 12,    /* snow_hydrology_impl.hh:388 vol_ice[i+i], i = 3 */
+  ELMO_WARN_SNOW_COMBINE_OOB = 1u << 13,  /* snow_hydrology_impl.hh:871-885 element -1 */
+  ELMO_ERR_SNOW_DIVIDE_RDS = 1u << 14,    /* snow_hydrology_impl.hh:1032, :1109, :1187, :1253 */
+  ELMO_ERR_SNOW_AGE_DRFRESH = 1u << 15    /* snow_hydrology_impl.hh:152 */
 };
 
 /* src/data/land_data.h:36-44 */
@@ -153,7 +160,13 @@ typedef struct {
   /* kokkos_init_timestep forcing + phenology functors: forcing records t_idx, t_idx + 1; months start_idx, + 1 */ \
   X(forc_hgt, D, 1) X(hbot, D, 1) X(atm_tbot, D, 2) X(atm_pbot, D, 2) X(atm_qbot, D, 2) X(atm_flds, D, 2)     \
   X(atm_fsds, D, 2) X(atm_prec, D, 2) X(atm_wind, D, 2) X(mlai, D, 2) X(msai, D, 2) X(mhtop, D, 2)            \
-  X(mhbot, D, 2)
+  X(mhbot, D, 2)                                                                                            \
+  /* kokkos_snow_hydrology: AerosolMasses, AerosolFileInput (aerosol_data.h:11-41), elm_state.h:151,160 */   \
+  X(mss_bcphi, D, 5) X(mss_bcpho, D, 5) X(mss_dst1, D, 5) X(mss_dst2, D, 5) X(mss_dst3, D, 5) X(mss_dst4, D, 5) \
+  X(aer_bcphi, D, 1) X(aer_bcpho, D, 1) X(aer_bcdep, D, 1) X(aer_dst1_1, D, 1) X(aer_dst1_2, D, 1)            \
+  X(aer_dst2_1, D, 1) X(aer_dst2_2, D, 1) X(aer_dst3_1, D, 1) X(aer_dst3_2, D, 1) X(aer_dst4_1, D, 1)         \
+  X(aer_dst4_2, D, 1) X(qflx_top_soil, D, 1) X(mflx_neg_snow, D, 1) X(qflx_snow2topsoi, D, 1)                 \
+  X(mflx_snowlyr_col, D, 1) X(qflx_rootsoi, D, 15)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -172,6 +185,8 @@ typedef struct elmo_state {
   double z0mr[ELMO_MXPFT], displar[ELMO_MXPFT];
   double albsat[ELMO_NSOILCOL][2], albdry[ELMO_NSOILCOL][2];
   elmo_snicar snicar;
+  /* SnwRdsTable (snicar_data.h:75-84): snowage_tau / kappa / drdt0 [idx_T 11][idx_Tgrd 31][idx_rhos 8], row-major */
+  double snowage[3][ELMO_SNOWAGE_N];
   /* per-column fields, [col][lev] */
 #define ELMO_DECL(name, kind, nlev) ELMO_CT_##kind *name;
   ELMO_FIELDS(ELMO_DECL)
@@ -211,6 +226,38 @@ void elmo_canopy_fluxes_given(elmo_state *S, double dt, const double *rho_in, co
                               const double *pco2_in, int *niter);
 void elmo_bareground_fluxes_given(elmo_state *S, const double *rho_in);
 void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha_out);
+/* kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188; ELMInterface::advance :313, between soil_temperature and
+ * surface_fluxes); elmo_physics_g.c.  PARITY UNPINNED (see that file's header). */
+void elmo_snow_hydrology(elmo_state *S, double dt);
+double *elmo_snowage_ptr(elmo_state *S); /* 3 x ELMO_SNOWAGE_N: tau, kappa, drdt0 */
+void elmo_snow_aging(int do_capsnow, int snl, double frac_sno, double dtime, double qflx_snwcp_ice, double qflx_snow_grnd,
+                     double h2osno, const double *dz, const double *h2osoi_liq, const double *h2osoi_ice,
+                     const double *t_soisno, const double *qflx_snofrz_lyr, const double *snowage_tau,
+                     const double *snowage_kappa, const double *snowage_drdt0, double *snw_rds, uint32_t *err);
+void elmo_snow_water(int do_capsnow, int snl, double dtime, double frac_sno_eff, double h2osno, double qflx_sub_snow,
+                     double qflx_evap_grnd, double qflx_dew_snow, double qflx_dew_grnd, double qflx_rain_grnd,
+                     double qflx_snomelt, double *qflx_snow_melt, double *qflx_top_soil, double *int_snow, double *frac_sno,
+                     double *mflx_neg_snow, double *h2osoi_liq, double *h2osoi_ice, double *mss_bcphi, double *mss_bcpho,
+                     double *mss_dst1, double *mss_dst2, double *mss_dst3, double *mss_dst4, double *dz, uint32_t *err);
+void elmo_aerosol_phase_change(int snl, double dtime, double qflx_sub_snow, const double *h2osoi_liq, const double *h2osoi_ice,
+                               double *mss_bcphi, double *mss_bcpho);
+void elmo_transpiration(int veg_active, double qflx_tran_veg, const double *rootr, double *qflx_rootsoi);
+void elmo_snow_compaction(int snl, int ltype, double dtime, double int_snow, double n_melt, double frac_sno, const int *imelt,
+                          const double *swe_old, const double *h2osoi_liq, const double *h2osoi_ice, const double *t_soisno,
+                          const double *frac_iceold, double *dz);
+void elmo_combine_layers(int urbpoi, int ltype, double dtime, int *snl, double *h2osno, double *snow_depth,
+                         double *frac_sno_eff, double *frac_sno, double *int_snow, double *qflx_sl_top_soil,
+                         double *qflx_snow2topsoi, double *mflx_snowlyr_col, double *t_soisno, double *h2osoi_ice,
+                         double *h2osoi_liq, double *snw_rds, double *mss_bcphi, double *mss_bcpho, double *mss_dst1,
+                         double *mss_dst2, double *mss_dst3, double *mss_dst4, double *dz, double *z, double *zi, uint32_t *err);
+void elmo_divide_layers(double frac_sno, int *snl, double *h2osoi_ice, double *h2osoi_liq, double *t_soisno, double *snw_rds,
+                        double *mss_bcphi, double *mss_bcpho, double *mss_dst1, double *mss_dst2, double *mss_dst3,
+                        double *mss_dst4, double *dz, double *z, double *zi, uint32_t *err);
+void elmo_prune_snow_layers(int snl, double *h2osoi_ice, double *h2osoi_liq, double *t_soisno, double *dz, double *z, double *zi);
+void elmo_aerosol_deposition(double dtime, int snl, const double *aer, double *mss_bcphi, double *mss_bcpho, double *mss_dst1,
+                             double *mss_dst2, double *mss_dst3, double *mss_dst4);
+void elmo_aerosol_mass_and_concen(double dtime, int snl, int do_capsnow, double qflx_snwcp_ice, const double *h2osoi_ice,
+                                  const double *h2osoi_liq, double *const mss[6], double *const cnc[6]);
 /* next row: soil_temperature_kokkos.cc:6-278 (follows the seven wrappers in ELMInterface::advance, :310) */
 void elmo_soil_temperature(elmo_state *S, double dt);
 /* the same with the intermediate system exposed, for the residual / energy-balance checks of the tests:

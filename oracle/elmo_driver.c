@@ -94,6 +94,7 @@ void *elmo_field_ptr(elmo_state *S, const char *name, int *nlev, int *kind)
 }
 
 elmo_snicar *elmo_snicar_ptr(elmo_state *S) { return &S->snicar; }
+double *elmo_snowage_ptr(elmo_state *S) { return &S->snowage[0][0]; }
 elmo_pft_psn *elmo_pft_psn_ptr(elmo_state *S) { return S->pft_psn; }
 elmo_pft_alb *elmo_pft_alb_ptr(elmo_state *S) { return S->pft_alb; }
 double *elmo_z0mr_ptr(elmo_state *S) { return S->z0mr; }
@@ -448,6 +449,50 @@ void elmo_soil_temperature_ex(elmo_state *S, double dt, double *lhs_out, double 
 }
 
 void elmo_soil_temperature(elmo_state *S, double dt) { elmo_soil_temperature_ex(S, dt, NULL, NULL, NULL, NULL, NULL); }
+
+/* snow_hydrology_kokkos.cc:23-188: snow_water; compute_aerosol_deposition; aerosol_phase_change, transpiration,
+ * snow_compaction, combine_layers, divide_layers, prune_snow_layers; update_aerosol_mass_and_concen; snow_aging - five
+ * parallel_for launches in the reference, one pass per column here (a column only reads what the same column wrote) */
+void elmo_snow_hydrology(elmo_state *S, double dt)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    uint32_t err = 0;
+    elmo_snow_water(S->do_capsnow[c], S->snl[c], dt, S->frac_sno_eff[c], S->h2osno[c], S->qflx_sub_snow[c],
+                    S->qflx_evap_grnd[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c], S->qflx_rain_grnd[c], S->qflx_snomelt[c],
+                    &S->qflx_snow_melt[c], &S->qflx_top_soil[c], &S->int_snow[c], &S->frac_sno[c], &S->mflx_neg_snow[c],
+                    LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5),
+                    LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5), LV(dz, 20), &err);
+    const double aer[11] = {S->aer_bcphi[c],  S->aer_bcpho[c],  S->aer_bcdep[c],  S->aer_dst1_1[c], S->aer_dst1_2[c], S->aer_dst2_1[c],
+                            S->aer_dst2_2[c], S->aer_dst3_1[c], S->aer_dst3_2[c], S->aer_dst4_1[c], S->aer_dst4_2[c]};
+    elmo_aerosol_deposition(dt, S->snl[c], aer, LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5),
+                            LV(mss_dst3, 5), LV(mss_dst4, 5));
+    elmo_aerosol_phase_change(S->snl[c], dt, S->qflx_sub_snow[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5),
+                              LV(mss_bcpho, 5));
+    elmo_transpiration(S->veg_active[c], S->qflx_tran_veg[c], LV(rootr, 15), LV(qflx_rootsoi, 15));
+    elmo_snow_compaction(S->snl[c], S->land.ltype, dt, S->int_snow[c], S->n_melt[c], S->frac_sno[c], LV(imelt, 20),
+                         LV(swe_old, 5), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(frac_iceold, 20),
+                         LV(dz, 20));
+    elmo_combine_layers(S->land.urbpoi, S->land.ltype, dt, &S->snl[c], &S->h2osno[c], &S->snow_depth[c], &S->frac_sno_eff[c],
+                        &S->frac_sno[c], &S->int_snow[c], &S->qflx_sl_top_soil[c], &S->qflx_snow2topsoi[c],
+                        &S->mflx_snowlyr_col[c], LV(t_soisno, 20), LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(snw_rds, 5),
+                        LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5),
+                        LV(mss_dst4, 5), LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), &err);
+    elmo_divide_layers(S->frac_sno[c], &S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(snw_rds, 5),
+                       LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5),
+                       LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), &err);
+    elmo_prune_snow_layers(S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(dz, 20), LV(zsoi, 20),
+                           LV(zisoi, 21));
+    double *const mss[6] = {LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5)};
+    double *const cnc[6] = {LV(cnc_bcphi, 5), LV(cnc_bcpho, 5), LV(cnc_dst1, 5), LV(cnc_dst2, 5), LV(cnc_dst3, 5), LV(cnc_dst4, 5)};
+    elmo_aerosol_mass_and_concen(dt, S->snl[c], S->do_capsnow[c], S->qflx_snwcp_ice[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20),
+                                 mss, cnc);
+    elmo_snow_aging(S->do_capsnow[c], S->snl[c], S->frac_sno[c], dt, S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c], S->h2osno[c],
+                    LV(dz, 20), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(qflx_snofrz_lyr, 5),
+                    S->snowage[0], S->snowage[1], S->snowage[2], LV(snw_rds, 5), &err);
+    S->err_flags[c] |= err;
+  }
+}
 
 /* surface_fluxes_kokkos.cc:5-107 */
 void elmo_surface_fluxes(elmo_state *S, double dt)

@@ -57,7 +57,7 @@ class _Lib:
         L.elmo_field_name.argtypes = [C.c_int]
         L.elmo_field_ptr.restype = C.c_void_p
         L.elmo_field_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        for n in ("snicar", "pft_psn", "pft_alb", "z0mr", "displar", "albsat", "albdry"):
+        for n in ("snicar", "pft_psn", "pft_alb", "z0mr", "displar", "albsat", "albdry", "snowage"):
             f = getattr(L, f"elmo_{n}_ptr")
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
@@ -72,6 +72,7 @@ class _Lib:
         L.elmo_bareground_fluxes_given.argtypes = [C.c_void_p, C.c_void_p]
         L.elmo_albedo_snicar_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elmo_soil_temperature.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_snow_hydrology.argtypes = [C.c_void_p, C.c_double]
         L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
         L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
         L.elmo_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
@@ -151,6 +152,8 @@ class OracleState:
         self.displar = _view(L.elmo_displar_ptr(self.ptr), (25,), np.float64)
         self.albsat = _view(L.elmo_albsat_ptr(self.ptr), (20, 2), np.float64)
         self.albdry = _view(L.elmo_albdry_ptr(self.ptr), (20, 2), np.float64)
+        # SnwRdsTable (snicar_data.h:75-84): snowage_tau / kappa / drdt0, each [11, 31, 8]
+        self.snowage = _view(L.elmo_snowage_ptr(self.ptr), (3, 11, 31, 8), np.float64)
         self.snicar = {}
         off = L.elmo_snicar_ptr(self.ptr)
         for name, n in SNICAR_TABLES:
@@ -196,6 +199,7 @@ class OracleState:
         self.albdry[...] = other.albdry
         for k in self.snicar:
             self.snicar[k][...] = other.snicar[k]
+        self.snowage[...] = other.snowage
         self.set_scalars(**other.scalars)
 
     def clone(self):
@@ -261,6 +265,10 @@ class OracleState:
                    hs=np.zeros((n, 4)))
         self._L.lib.elmo_soil_temperature_ex(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "sol", "cv", "hs")])
         return out
+
+    def snow_hydrology(self, dt):
+        """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188); parity unpinned (oracle/elmo_physics_g.c)."""
+        self._L.lib.elmo_snow_hydrology(self.ptr, float(dt))
 
     def init_timestep(self, lib=None):
         (self._L.lib.elmo_init_timestep if lib is None else lib.elmref_init_timestep)(self.ptr)

@@ -24,6 +24,7 @@ def oracle_state(cols, scal, soil, land=None, pft=None, optics=None):
     S.albsat[:] = soil["albsat"]
     S.albdry[:] = soil["albdry"]
     S.set_scalars(**(land or synth.TEST_LAND), **scal)
+    S.snowage[...] = synth.snow_age_tables()
     for k, v in cols.items():
         S.fields[k][...] = v
     return S
@@ -38,6 +39,7 @@ def device_state(cols, scal, soil, land=None, device=0):
     D.set_soilcolor(soil["albsat"], soil["albdry"])
     D.set_land(**(land or synth.TEST_LAND))
     D.set_scalars(**scal)
+    D.set_snow_age_tables(synth.snow_age_tables())
     for k, v in cols.items():
         D[k] = v
     return D

@@ -109,6 +109,74 @@ def test_advance_chain_bit_identical():
     D.close()
 
 
+@pytest.mark.parametrize("tier,n,seed", [("A", 4700, 41), ("B", 20000, 42), ("B", 1001, 43)])
+def test_snow_hydrology_next_row(tier, n, seed):
+    """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188) on bit-identical inputs: the state after the seven wrappers and
+    the temperature solve (so that imelt, swe_old, frac_iceold, qflx_snomelt ... are what the step produced).  Every field
+    bit-identical to the oracle's restatement, the new flag bits included (the oracle itself is parity-unpinned against the
+    reference for this row: oracle/elmo_physics_g.c)."""
+    D, S = _pair(n, tier, seed)
+    S.timestep7(DT)
+    S.soil_temperature(DT)
+    for k, v in S.fields.items():
+        if k != "err_flags":
+            D[k] = v
+    snl0 = S["snl"].copy()
+    st.kokkos_snow_hydrology(D, DT)
+    S.snow_hydrology(DT)
+    _check(D, S, f"snow_hydrology {tier}/{n}", bitwise=True)
+    assert np.array_equal(D["err_flags"], S["err_flags"] & np.uint32(0xF000))  # (the device flags were clear before the call)
+    if tier == "B":
+        assert (S["snl"] != snl0).sum() > n // 100 and (S["err_flags"] & (1 << 12)).any()
+    D.close()
+
+
+def test_snow_hydrology_other_land_units():
+    """combine_layers treats soil / crop / urban and wetland / land-ice units differently (where the water of a vanishing
+    layer goes, snow_hydrology_impl.hh:675-720, :760-775)."""
+    for land in (dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0), dict(ltype=3, ctype=0, vtype=0, urbpoi=0, lakpoi=0),
+                 dict(ltype=7, ctype=71, vtype=0, urbpoi=1, lakpoi=0), dict(ltype=2, ctype=0, vtype=15, urbpoi=0, lakpoi=0)):
+        D, S = _pair(3000, "B", 44, land)
+        S["h2osoi_ice"][::7, :5] *= 0.001  # thin-ice layers: the first loop of combine_layers
+        for k, v in S.fields.items():
+            if k != "err_flags":
+                D[k] = v
+        st.kokkos_snow_hydrology(D, DT)
+        S.snow_hydrology(DT)
+        _check(D, S, f"snow_hydrology, land {land}", bitwise=True)
+        D.close()
+
+
+def test_advance_chain_with_snow_hydrology():
+    """The reference's whole advance() order (elm_kokkos_interface.cc:278-318) - init_timestep, the seven wrappers,
+    soil_temperature, snow_hydrology, surface_fluxes - chained for twelve steps with no re-synchronisation: the snow pack
+    is re-meshed on the device step after step (layers appear, merge, split, vanish) and every field stays bit-identical
+    to the oracle chain.  The forcing heights are put back before each step, as the driver does (atm_physics_impl.hh:197-203)."""
+    n = 6016
+    D, S = _pair(n, "B", 14)
+    hgt = {k: S[k].copy() for k in ("forc_hgt_u_patch", "forc_hgt_t_patch", "forc_hgt_q_patch")}
+    snl_hist = []
+    for step in range(12):
+        for k, v in hgt.items():
+            D[k] = v
+            S[k][...] = v
+        st.kokkos_init_timestep(D)
+        S.init_timestep()
+        (st.timestep7_fused if step % 2 else st.timestep7)(D, DT)
+        S.timestep7(DT)
+        st.kokkos_soil_temperature(D, DT)
+        S.soil_temperature(DT)
+        st.kokkos_snow_hydrology(D, DT)
+        S.snow_hydrology(DT)
+        st.kokkos_surface_fluxes(D, DT)
+        S.surface_fluxes(DT)
+        _check(D, S, f"advance chain with snow hydrology, step {step}", bitwise=True)
+        snl_hist.append(S["snl"].copy())
+    changed = sum(int((a != b).sum()) for a, b in zip(snl_hist, snl_hist[1:]))
+    assert changed > 50  # the mesh really moved between steps
+    D.close()
+
+
 def test_other_land_units():
     """Non-soil land units take the short branches of every routine (wetland, land ice, lake, urban)."""
     for land in (dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0), dict(ltype=3, ctype=0, vtype=0, urbpoi=0, lakpoi=0),

@@ -349,6 +349,42 @@ def test_tiling_invariance_at_scale():
     Dbase.close(); big.close()
 
 
+def test_tiling_invariance_at_the_north_star_size():
+    """The same property at the north-star size, 10 M columns (BASELINE configs 3 / 5: 64 GB of device state), through the rest
+    of advance() as well: the fused step, the soil-column temperature solve, snow hydrology and surface fluxes on 10 M
+    columns must reproduce the base block's results in every tile, bit for bit."""
+    ft = st.field_table()
+    nbase, n = 6016, 10_000_000
+    cols, scal, soil = synth.make_state(ft, nbase, tier="B", seed=78)
+    Dbase = H.device_state(cols, scal, soil)
+    big = st.ELMState(n)
+    pft, optics = synth.load_params()
+    big.set_pft(pft); big.set_snicar(optics); big.set_soilcolor(soil["albsat"], soil["albdry"])
+    big.set_land(**synth.TEST_LAND); big.set_scalars(**scal)
+    big.set_snow_age_tables(synth.snow_age_tables())
+    for k, v in cols.items():
+        big.upload(k, v, col0=0)
+    big.tile_columns(nbase, rules=())
+    for D in (Dbase, big):
+        st.kokkos_init_timestep(D)
+        st.timestep7_fused(D, DT)
+        st.kokkos_soil_temperature(D, DT)
+        st.kokkos_snow_hydrology(D, DT)
+        st.kokkos_surface_fluxes(D, DT)
+    idx = np.arange(n) % nbase
+    for name in ("t_veg", "h2osno", "cgrnd", "snl", "t_grnd", "xmf", "snow_depth", "eflx_soil_grnd", "qflx_top_soil", "btran"):
+        assert np.array_equal(big[name], Dbase[name][idx], equal_nan=True), name
+    # level arrays: a window at the far end of the state (the last tiles) instead of 1.6 GB per field
+    w0, wn = n - 200_000, 200_000
+    for name in ("t_soisno", "h2osoi_ice", "dz", "snw_rds", "mss_bcphi", "imelt", "sabg_lyr"):
+        got = big.download(name, col0=w0, n=wn)
+        assert np.array_equal(got, Dbase[name][idx[w0:]], equal_nan=True), name
+    fb, _ = Dbase.error_summary()
+    fl, _ = big.error_summary()
+    assert fb == fl and big.device_bytes > 60e9
+    Dbase.close(); big.close()
+
+
 @pytest.mark.parametrize("n", [1, 63, 65, 257, 1000])
 def test_ragged_sizes(n):
     """Column counts that are not multiples of the wave (64) or workgroup (256) size: the padded tail of every level
@@ -660,6 +696,10 @@ def test_device_math_bits():
     the device returns the BITS of the host libm the oracle (and the reference) calls (elmkernels_amd/csrc/elmk_math.h
     restates glibc's algorithms).  Arguments: the ranges the physics uses, the whole exponent range, random bit
     patterns, specials.  (cos is restated for |x| < 105414350, see the header.)"""
+    from tests import _parity_mode
+
+    if not _parity_mode.BITWISE_VALID:
+        pytest.skip("the host libm is not the one elmk_math.h restates (tests/test_math_host.py is the guard for that)")
     m = _libm()
     rng = np.random.default_rng(20261004)
     n = 200_000

@@ -174,7 +174,7 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
   }
 }
 
-__global__ __launch_bounds__(ST_WG, 3) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
+__global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
 {
   elmk_math_lds_init<false>();  // pow in the surface heat fluxes and in the supercooled-water limit of phase change
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# In the build container, after `gpurun -- bash tests/tools/profile_round.sh <tag>`: only gpurun_out/ travels back from the GPU
+# box, so copy the files to be committed from gpurun_out/<tag>/ into profiles/ with the round prefix.
+# bash tests/tools/collect_profiles.sh <tag>
+set -e
+T=${1:-prof}
+P=${PROFILE_TAG:-r02}
+O=gpurun_out/$T
+for f in hbm_traffic_pmc_tierA.json hbm_traffic_pmc_tierB.json hbm_traffic_pmc_fused_tierA.json hbm_traffic_pmc_fused_tierB.json \
+         hbm_traffic_pmc_soil_tierB.json bench_1M.json bench_1M_rocprof_kernel_stats.csv bench_1M_fused_rocprof_kernel_stats.csv \
+         bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json; do
+  cp $O/$f profiles/${P}_$f
+done
+ls profiles | grep "^${P}_"

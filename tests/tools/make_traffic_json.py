@@ -8,6 +8,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import bench  # noqa: E402  (kernel_source_hash: the table is only valid for the build it was measured on)
+
 
 def per_kernel(root, counter):
     acc = collections.defaultdict(list)
@@ -30,6 +33,7 @@ out = {
             "1 GiB written with the kernels' own 8-byte-per-lane access shape): FETCH_SIZE reads exactly 1/2 of the bytes, "
             "WRITE_SIZE reads them exactly (as MI355X_MICROARCH.md says for wide streams) -> "
             "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.",
+    "source_hash": bench.kernel_source_hash(),
     "kernels": {},
 }
 for k in sorted(set(fetch) | set(write)):

@@ -10,10 +10,19 @@ from elmkernels_amd import state as st  # noqa: E402
 
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tier = sys.argv[2] if len(sys.argv) > 2 else "B"
+mode = sys.argv[3] if len(sys.argv) > 3 else "timestep7"  # timestep7 | fused | soil
 D, _ = bench.build_state(cols, 0, tier, 0x5EEDE1A0)
 print("copy GB/s (1 GiB buffers, 8 B/lane):", D.copy_bandwidth(1 << 30, 5))
-for _ in range(3):
-    D.restore_fields()
+if mode == "soil":
     st.timestep7(D, 1800.0)
+    D.snapshot_fields(bench.SOIL_RESTORE)
+    for _ in range(3):
+        D.restore_fields()
+        st.kokkos_soil_temperature(D, 1800.0)
+else:
+    adv = st.timestep7_fused if mode == "fused" else st.timestep7
+    for _ in range(8):  # (the canopy_fluxes scheduling hints settle over a few steps)
+        D.restore_fields()
+        adv(D, 1800.0)
 D.sync()
 print("done")

@@ -227,9 +227,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   const size_t cls_bytes = align_up((size_t)ctx->ld, 256);
   const size_t given_bytes = align_up((size_t)3 * (size_t)ctx->ld * 8, 256);
   const size_t snow_bytes = align_up((size_t)28 * (size_t)ctx->ld * 8, 256);
-  const size_t stw_bytes = align_up((size_t)(40 + 42) * (size_t)ctx->ld * 8, 256);  // soil_temperature: thk, cv of the 20 levels; A, Z of the 21 rows
   const size_t cons_bytes = align_up((size_t)8 * (size_t)ctx->ld * 8 + (size_t)8 * ELMK_CONS_NPART * 3 * 8 + 8 * 3 * 8, 256);
-  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + cls_bytes + given_bytes + snow_bytes + stw_bytes + cons_bytes;
+  ctx->scratch_bytes = wk_bytes + list_bytes + cnt_bytes + hint_bytes + rec_bytes + fin_bytes + irec_bytes + pos_bytes + blk_bytes + cls_bytes + given_bytes + snow_bytes + cons_bytes;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->scratch, ctx->scratch_bytes), "hipMalloc(scratch)")) return fail(ELMK_E_NOMEM);
   if (hip_fail(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, ctx->stream), "hipMemset(scratch)"))
     return fail(ELMK_E_HIP);
@@ -275,8 +274,6 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
     q += given_bytes;
     h.alb_snow = (gptr<double>)q;
     q += snow_bytes;
-    h.st_work = (gptr<double>)q;
-    q += stw_bytes;
     h.cons_diag = (gptr<double>)q;
     h.cf_nblk = cf_nblk;
   }

@@ -189,7 +189,6 @@ struct DevState {
   gptr<int32_t> lists;      // NLISTS column-index lists, each ld entries (work queues of the compacted kernels)
   gptr<uint32_t> counters;  // list lengths and queue heads (ELMK_LIST_COUNT / ELMK_LIST_HEAD)
   gptr<double> cons_diag;   // 8 x ld: conservation diagnostics per column (k_surface_fluxes.hip)
-  gptr<double> st_work;     // 82 x ld: thk, cv of the 20 levels (soil_temperature stage 1), then A, Z of the 21 rows of the forward sweep (k_soil_temperature.hip), [row][column]
   gptr<double> alb_snow;    // 28 x ld: SNICAR products of the sunlit snow-covered columns (k_albedo_snicar.hip), by column
   gptr<int32_t> cf_niter;   // canopy_fluxes trip count of each column in the previous call (scheduling hint only)
   gptr<double> cf_rec;      // CF_REC_N x ld: inputs of the queued columns, by queue position

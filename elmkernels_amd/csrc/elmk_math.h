@@ -454,7 +454,7 @@ ELMK_MFN double elmk_pow_general(double x, double y)
 // everything the physics does - log_inline and exp_inline run as one straight-line block; any other argument takes the
 // single branch to the general form afterwards.
 // main path as a branch-free block; `rare` set for every argument pair outside it
-ELMK_MFN double elmk_pow_main(double x, double y, int* rare)
+ELMK_MFN double elmk_pow_main_tab(double x, double y, int* rare, const uint64_t* powlog_tab)
 {
   const uint64_t ix = elmk_asu64(x);
   const uint32_t topx = (uint32_t)(ix >> 52);
@@ -469,8 +469,8 @@ ELMK_MFN double elmk_pow_main(double x, double y, int* rare)
   const uint64_t iz = ix - (tmp & 0xfffull << 52);
   const double z = elmk_asf64(iz);
   const double kd = (double)k;
-  const double invc = elmk_asf64(ELMK_T_POWLOG[3 * i]), logc = elmk_asf64(ELMK_T_POWLOG[3 * i + 1]),
-               logctail = elmk_asf64(ELMK_T_POWLOG[3 * i + 2]);
+  const double invc = elmk_asf64(powlog_tab[3 * i]), logc = elmk_asf64(powlog_tab[3 * i + 1]),
+               logctail = elmk_asf64(powlog_tab[3 * i + 2]);
   const double r = ELMK_FMA(z, invc, -1.0);
   const double t1 = ELMK_FMA(kd, Ln2hi, logc);
   const double t2 = t1 + r;
@@ -514,10 +514,21 @@ ELMK_MFN double elmk_pow_main(double x, double y, int* rare)
   *rare = rare_arg | (abstop - 0x3c9u >= 0x3fu);
   return ELMK_FMA(scale, etmp, scale);
 }
+ELMK_MFN double elmk_pow_main(double x, double y, int* rare) { return elmk_pow_main_tab(x, y, rare, ELMK_T_POWLOG); }
 ELMK_MFN double elmk_pow(double x, double y)
 {
   int rare;
   double res = elmk_pow_main(x, y, &rare);
+  if (__builtin_expect(rare, 0)) res = elmk_pow_general(x, y);
+  return res;
+}
+// pow with a base that is a literal in the source: same bits.  log_inline reads the read-only table in global memory whatever
+// ELMK_MATH_LDS says, so that the compiler evaluates the whole logarithm (table row, polynomial, hi + lo split) at compile time
+// and only y log x and exp_inline are left to run.
+ELMK_MFN double elmk_pow_literal_base(const double x, double y)
+{
+  int rare;
+  double res = elmk_pow_main_tab(x, y, &rare, elmk_powlog_tab);
   if (__builtin_expect(rare, 0)) res = elmk_pow_general(x, y);
   return res;
 }

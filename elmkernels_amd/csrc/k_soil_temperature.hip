@@ -12,13 +12,19 @@
 //   soil_temp::phase_change_h2osfc :11, phase_change_soisno :182   (src/physics/phase_change_impl.hh)
 //
 // The reference runs nine parallel_for launches and materialises tk, cv, fn, rhs[21], lhs[21][5], A, B, Z and ten
-// more scratch Views in memory.  Here one thread owns one column and goes down it once: the thermal properties of a
-// level, its matrix factor, the diffusive fluxes across its faces and its row of the 21-row, 5-band system (snow
-// layers, standing surface water, soil layers) are formed from a sliding window of three levels and pushed straight
-// into the forward sweep; back substitution and phase change (its three loops fused level by level) follow, level by
-// level.  All level loops are rolled - the level index is the same for every lane, so its branches are uniform and
-// every access is a coalesced row of the SoA state - and the sweep's A, B, Z (63 doubles per column) go through the
-// context's scratch instead of a register array, which keeps the kernel small enough for several waves per SIMD.
+// more scratch Views in memory.  Here ONE launch does the wrapper, one thread per column going down it once: the raw
+// inputs of a level arrive as one row of coalesced loads two levels ahead of their use, its thermal properties (the
+// transcendental work: two pow and a log10 per soil level), its matrix factor, the diffusive fluxes across its faces
+// and its row of the 21-row, 5-band system (snow layers, standing surface water, soil layers) are formed from a
+// sliding window of three levels and pushed straight into the forward sweep, whose A and Z stay in LDS; the back
+// substitution leaves the new temperatures in the same LDS rows, and phase change (its three loops fused level by
+// level) is the only pass that writes temperature, ice and liquid back.  Per column the kernel reads each input once
+// (ice, liquid and the matrix factor a second time for phase change: no on-chip room for them) and writes each output
+// once - 3.5 KB measured against the 2.9 KB tally of DESIGN.md section 9.
+// All level loops are rolled and unrolled by two - the level index is the same for every lane, so its branches are
+// uniform and every access is a coalesced row of the SoA state; the two alternating register sets of the unrolled loops
+// are the software pipeline (st_load_level).  A workgroup is eight waves sharing one copy of the math tables:
+// 2 x 19 rows x 512 lanes x 8 B + 7 KB = 159 KB of LDS, one workgroup per CU, two waves per SIMD with no spill.
 // The number of active snow layers differs from lane to lane, so loops that the reference starts at the top active
 // layer run over all rows with a predicate, and rows above the snow pack enter the forward sweep as identity rows:
 // with their A, B, Z equal to zero the general recurrence reproduces the reference's special first and second rows
@@ -52,35 +58,65 @@ __device__ __forceinline__ double st_surface_heat_flux(int frac_veg_nosno, doubl
          (eflx_sh + qflx_ev * htvp);
 }
 
+// what the sweep reads of one level, issued as one row of loads three levels ahead of its use (the level index is the same
+// for every lane, so the soil-only fields sit behind a uniform branch; levels above the snow pack are never read)
+struct StLevIn {
+  double liq, ice, dz, t, z, zi, sabg, watsat, tkdry, tkmg, csol;
+};
+
+__device__ __forceinline__ StLevIn st_load_level(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int i,
+                                                 const int top)
+{
+  // No branch around any load: the compiler can only count the loads in flight (s_waitcnt vmcnt) along straight-line code.
+  // Levels past the bottom re-read the bottom level, lanes whose snow pack starts below level i read the top soil level
+  // (always there, and theirs to read a few trips later anyway); none of those values is used.
+  const int lv = (i < NLEVTOT) ? i : NLEVTOT - 1;
+  const int li = (lv >= top) ? lv : NLEVSNO;
+  const int js = (li >= NLEVSNO) ? li - NLEVSNO : 0;
+  const int lsab = (li <= NLEVSNO) ? li : NLEVSNO;
+  const int lcs = (li >= NLEVSNO) ? li : NLEVSNO;
+  StLevIn L;
+  L.liq = LV(h2osoi_liq, li);
+  L.ice = LV(h2osoi_ice, li);
+  L.dz = LV(dz, li);
+  L.t = LV(t_soisno, li);
+  L.z = LV(zsoi, li);
+  L.zi = LV(zisoi, li);
+  L.sabg = LV(sabg_lyr, lsab);
+  L.watsat = LV(watsat, js);
+  L.tkdry = LV(tkdry, js);
+  L.tkmg = LV(tkmg, js);
+  L.csol = LV(csol, lcs);
+  return L;
+}
+
 // thermal conductivity and heat capacity of level i (soil_thermal_properties_impl.hh: calc_soil_tk :20 and
 // calc_soil_heat_capacity :163 with the wrapper's ltype == 1, calc_snow_tk :96, calc_snow_heat_capacity :206).
 // i is the same for every lane (the level loops are rolled), so the branches on it are uniform.
-__device__ __forceinline__ void st_level_props(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int i,
-                                               const int top, const int snl, const double frac_sno, const double h2osno,
-                                               double& thk, double& cv)
+__device__ __forceinline__ void st_level_props(const StLevIn& L, const int i, const int top, const int snl, const double frac_sno,
+                                               const double h2osno, double& thk, double& cv)
 {
-  const double liq = LV(h2osoi_liq, i), ice = LV(h2osoi_ice, i), dzl = LV(dz, i);
+  const double liq = L.liq, ice = L.ice, dzl = L.dz;
   if (i >= NLEVSNO) {
-    const int j = i - NLEVSNO;
-    const double watsat = LV(watsat, j);
+    const double watsat = L.watsat;
     double satw = (liq / DENH2O + ice / DENICE) / (dzl * watsat);
     satw = dmin(1.0, satw);
-    const double tkdry = LV(tkdry, j);
+    const double tkdry = L.tkdry;
     if (satw > 1.0e-6) {
       double dke;
-      if (LV(t_soisno, i) >= TFRZ) {
+      if (L.t >= TFRZ) {
         dke = dmax(0.0, elmk_log10(satw) + 1.0);
       } else {
         dke = satw;
       }
       const double fl = (liq / (DENH2O * dzl)) / (liq / (DENH2O * dzl) + ice / (DENICE * dzl));
-      const double dksat = LV(tkmg, j) * elmk_pow(ST_TKWAT, fl * watsat) * elmk_pow(ST_TKICE, (1.0 - fl) * watsat);
+      const double dksat = L.tkmg * elmk_pow_literal_base(ST_TKWAT, fl * watsat) * elmk_pow_literal_base(ST_TKICE, (1.0 - fl) * watsat);
       thk = dke * dksat + (1.0 - dke) * tkdry;
     } else {
       thk = tkdry;
     }
     if (i >= NLEVSNO + NLEVBED) thk = ST_TKBDRK;
-    cv = LV(csol, i) * (1.0 - watsat) * dzl + (ice * ST_CPICE + liq * ST_CPWAT);
+    cv = L.csol * (1.0 - watsat) * dzl + (ice * ST_CPICE + liq * ST_CPWAT);
     if (i == NLEVSNO && snl == 0 && h2osno > 0.0) cv += ST_CPICE * h2osno;
   } else {
     if (i < top) {
@@ -98,49 +134,26 @@ __device__ __forceinline__ void st_level_props(const DevState* __restrict__ S, c
   }
 }
 
-// Stage 1 of the wrapper: thermal conductivity and heat capacity of every (level, column), one thread each.  The level is
-// blockIdx.y - the same for the whole workgroup - so branches on it are uniform and every access is a coalesced row.
-// This is where the transcendental work of the wrapper is (two pow and a log10 per soil level); as a launch of its own
-// it runs at full occupancy beside its loads instead of serialised down the column inside the solve.
-// Results: rows ST_ROW_THK + i and ST_ROW_CV + i of the context's st_work scratch.
-constexpr int ST_ROW_THK = 0;
-constexpr int ST_ROW_CV = NLEVTOT;
-__global__ __launch_bounds__(256) void k_st_props(const DevState* __restrict__ S)
-{
-  elmk_math_lds_init<false>();
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t ld = S->ld;
-  if (c >= S->ncols) return;
-  const int i = (int)blockIdx.y;
-  const int snl = S->snl[c];
-  double thk, cv;
-  st_level_props(S, c, ld, i, NLEVSNO - snl, snl, S->frac_sno[c], S->h2osno[c], thk, cv);
-  S->st_work[(int64_t)(ST_ROW_THK + i) * ld + c] = thk;
-  S->st_work[(int64_t)(ST_ROW_CV + i) * ld + c] = cv;
-}
-
-// state of the forward sweep of solver::PDMA (pentadiagonal_solver_impl.hh:16-76).  A and Z of rows 0..18 go to the
-// context's scratch (SoA [row][column] like the state: the row loops are rolled, a register array would need dynamic
-// indexing; an LDS stage [row][thread] was measured: 78 KB per workgroup leaves two waves per SIMD and the solve, which
-// is latency-bound, ran 1.5 x slower).  B = l0 * U1 is zero in every row but one - only the snow layer next to the
+// state of the forward sweep of solver::PDMA (pentadiagonal_solver_impl.hh:16-76).  A and Z of rows 0..18 stay in LDS,
+// [row][lane] (the row loops are rolled, a register array would need dynamic indexing; [row][lane] is conflict-free).
+// The back substitution overwrites Z(r) with the solution of row r, so the new temperatures never leave the CU
+// before phase change has had them.  B = l0 * U1 is zero in every row but one - only the snow layer next to the
 // ground has a second superdiagonal entry (l0, get_matrix_snow_soil) - so that one value stays in a register and the
 // back substitution multiplies by a literal zero elsewhere (the same arithmetic as the reference's 0 * U1 product for
 // every finite solution).  The recurrence itself only needs the last two rows, kept here.
-constexpr int ST_ROW_A = 2 * NLEVTOT;        // rows of st_work after thk, cv
-constexpr int ST_ROW_Z = 2 * NLEVTOT + NROW;
+constexpr int ST_WG = 512;
+constexpr int ST_LDS_ROWS = NROW - 2;
+typedef double StLds[ST_LDS_ROWS][ST_WG];
 struct StSweep {
-  gptr<double> A;  // scratch bases of this column; element of row r at [r * ld]
-  gptr<double> Z;
   double B4;  // B of row NLEVSNO - 1
   double Am2, Am1, Bm2, Bm1, Zm2, Zm1;
   double Y1, U1, r19, l4_19, A19;  // kept from the second row from the bottom for the reference's form of the last two
 };
-constexpr int ST_WG = 256;
 
 // one row of the forward sweep.  Rows above the snow pack arrive as identity rows; with their A, B, Z equal to zero
 // the general recurrence gives the reference's special first and second rows exactly.
-__device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const int r, const double l0, const double l1,
-                                            const double l2, const double l3, const double l4, const double rr)
+__device__ __forceinline__ void st_push_row(StSweep& w, StLds& sA, StLds& sZ, const int lane, const int r, const double l0,
+                                            const double l1, const double l2, const double l3, const double l4, const double rr)
 {
   constexpr int N = NROW;
   if (r < N - 2) {
@@ -149,8 +162,8 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
     const double a = (l1 - w.Bm1 * Y1) * U1;
     const double b = l0 * U1;
     const double z = (rr - w.Zm2 * l4 - w.Zm1 * Y1) * U1;
-    w.A[(int64_t)r * ld] = a;
-    w.Z[(int64_t)r * ld] = z;
+    sA[r][lane] = a;
+    sZ[r][lane] = z;
     if (r == NLEVSNO - 1) w.B4 = b;
     w.Am2 = w.Am1;
     w.Am1 = a;
@@ -174,15 +187,47 @@ __device__ __forceinline__ void st_push_row(StSweep& w, const int64_t ld, const 
   }
 }
 
-__global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
+// what phase_change_soisno reads of one level beside its temperature (which is in LDS); the inputs of the supercooled-water
+// limit are only read for soil levels below freezing
+struct StPcIn {
+  double ice, liq, fact, watsat, sucsat, bsw, dz;
+};
+
+__device__ __forceinline__ StPcIn st_load_pc(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int i,
+                                             const int top, const double t)
 {
-  elmk_math_lds_init<false>();  // pow in the surface heat fluxes and in the supercooled-water limit of phase change
+  // branch-free like st_load_level; lanes that do not need the supercooled-water inputs all read element 0 (one line)
+  const int lv = (i < NLEVTOT) ? i : NLEVTOT - 1;
+  const int li = (lv >= top) ? lv : NLEVSNO;
+  const bool need = (lv >= NLEVSNO) && (t < TFRZ);
+  const int64_t js = need ? (int64_t)(li - NLEVSNO) * ld + c : 0;
+  const int64_t jd = need ? (int64_t)li * ld + c : 0;
+  StPcIn P;
+  P.ice = LV(h2osoi_ice, li);
+  P.liq = LV(h2osoi_liq, li);
+  P.fact = LV(fact, li);
+  P.watsat = S->watsat[js];
+  P.sucsat = S->sucsat[js];
+  P.bsw = S->bsw[js];
+  P.dz = S->dz[jd];
+  return P;
+}
+
+__global__ __launch_bounds__(ST_WG, 2) void k_soil_temperature(const DevState* __restrict__ S, double dtime)
+{
+  __shared__ StLds sA, sZ;
+  elmk_math_lds_init<false>();  // pow and log10 in the thermal properties, the surface heat fluxes and the supercooled-water limit
+  const int lane = (int)threadIdx.x;
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   if (c >= S->ncols) return;
   // (the wrapper's "dummy ltype" is 1 - istsoil - for every column, soil_temperature_kokkos.cc:77-79)
   const int snl = S->snl[c];
   const int top = NLEVSNO - snl;
+  // the first three levels' inputs: in flight while the column scalars arrive and the surface fluxes are formed
+  const StLevIn in0 = st_load_level(S, c, ld, 0, top);
+  StLevIn inX = st_load_level(S, c, ld, 1, top);
+  StLevIn inY = st_load_level(S, c, ld, 2, top);
   const double frac_sno = S->frac_sno[c], frac_sno_eff = S->frac_sno_eff[c], frac_h2osfc = S->frac_h2osfc[c];
   const double h2osfc0 = S->h2osfc[c], h2osno0 = S->h2osno[c];
   const double onemcn = 1.0 - ST_CNFAC;
@@ -217,32 +262,25 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
   // ---- one pass down the column: thermal properties, matrix factor, diffusive fluxes, the row of the system
   //      (rows 0..4 snow, row 5 standing surface water, rows 6..20 soil; band 0 = 2nd superdiagonal, 1 = 1st
   //      superdiagonal, 2 = diagonal, 3 = 1st subdiagonal, 4 = 2nd subdiagonal) and the forward sweep.  Only the
-  //      sweep's A, B, Z stay in registers; level quantities live in a sliding window (previous, current, next).
+  //      sweep's recurrence stays in registers; level quantities live in a sliding window (previous, current, next),
+  //      and the raw inputs of levels i + 2 .. i + 4 are the loads in flight.
   StSweep w;
-  w.A = S->st_work + (int64_t)ST_ROW_A * ld + c;
-  w.Z = S->st_work + (int64_t)ST_ROW_Z * ld + c;
   w.B4 = 0.0;
   w.Am2 = w.Am1 = w.Bm2 = w.Bm1 = w.Zm2 = w.Zm1 = 0.0;
   w.Y1 = w.U1 = w.r19 = w.l4_19 = w.A19 = 0.0;
   double fact_sl1 = 0.0;  // matrix factor of the snow layer next to the ground (for phase_change_h2osfc)
-  const gptr<const double> props = S->st_work + c;  // stage 1 (k_st_props): rows ST_ROW_THK + i, ST_ROW_CV + i
-  double thk_cur = props[(int64_t)ST_ROW_THK * ld], cv_cur = props[(int64_t)ST_ROW_CV * ld];
-  double z_cur = LV(zsoi, 0), t_cur = LV(t_soisno, 0);
+  double thk_cur, cv_cur;
+  st_level_props(in0, 0, top, snl, frac_sno, h2osno0, thk_cur, cv_cur);
+  double z_cur = in0.z, t_cur = in0.t, zi_cur = in0.zi, dz_cur = in0.dz, sabg_cur = in0.sabg;
   double z_prev = 0.0, tk_prev = 0.0, fn_prev = 0.0;
-  // the level loop is a dependent chain with little work per level: the loads of level i + 2 are issued one trip ahead
-  // of their use (software pipeline), so a wave always has a row of loads in flight
-  double thk_nxt = props[(int64_t)(ST_ROW_THK + 1) * ld], cv_nxt = props[(int64_t)(ST_ROW_CV + 1) * ld];
-  double z_nxt = LV(zsoi, 1), t_nxt = LV(t_soisno, 1), zi_nxt = LV(zisoi, 1);
-#pragma unroll 1
-  for (int i = 0; i < NLEVTOT; i++) {
-    double thk_n2 = 0.0, cv_n2 = 0.0, z_n2 = 0.0, t_n2 = 0.0, zi_n2 = 0.0;
-    if (i + 2 < NLEVTOT) {
-      thk_n2 = props[(int64_t)(ST_ROW_THK + i + 2) * ld];
-      cv_n2 = props[(int64_t)(ST_ROW_CV + i + 2) * ld];
-      z_n2 = LV(zsoi, i + 2);
-      t_n2 = LV(t_soisno, i + 2);
-      zi_n2 = LV(zisoi, i + 2);
-    }
+  // One level of the pass.  nx holds the inputs of level i + 1; as soon as they are consumed the same registers take the
+  // loads of level i + 3.  Two such sets alternate (the loop below is unrolled by two), so a set is never copied - a copy
+  // would have to wait for the loads it copies - and the rows of levels i + 2 and i + 3 are in flight during level i.
+  auto sweep_level = [&](const int i, StLevIn& nx) __attribute__((always_inline)) {
+    double thk_nxt = 0.0, cv_nxt = 0.0;
+    if (i + 1 < NLEVTOT) st_level_props(nx, i + 1, top, snl, frac_sno, h2osno0, thk_nxt, cv_nxt);
+    const double z_nxt = nx.z, t_nxt = nx.t, zi_nxt = nx.zi, dz_nxt = nx.dz, sabg_nxt = nx.sabg;
+    nx = st_load_level(S, c, ld, i + 3, top);
     // calc_face_tk (:132), calc_diffusive_heat_flux (soil_temperature_impl.hh:45): interface i | i+1
     double tk_i = 0.0, fn_i = 0.0;
     if (i < NLEVTOT - 1 && i >= top) {
@@ -255,8 +293,8 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
     if (i < top) {
       fact_i = 0.0;
     } else if (i == top) {
-      const double zit = LV(zisoi, i);
-      fact_i = dtime / cv_cur * LV(dz, i) / (0.5 * (z_cur - zit + ST_CAPR * (z_nxt - zit)));
+      const double zit = zi_cur;
+      fact_i = dtime / cv_cur * dz_cur / (0.5 * (z_cur - zit + ST_CAPR * (z_nxt - zit)));
     } else {
       fact_i = dtime / cv_cur;
     }
@@ -274,13 +312,13 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
       } else {
         const double dzm = z_cur - z_prev;
         const double dzp = z_nxt - z_cur;
-        rr = t_cur + ST_CNFAC * fact_i * (fn_i - fn_prev) + fact_i * LV(sabg_lyr, i);
+        rr = t_cur + ST_CNFAC * fact_i * (fn_i - fn_prev) + fact_i * sabg_cur;
         l3 = -onemcn * fact_i * tk_prev / dzm;
         l2 = 1.0 + onemcn * fact_i * (tk_i / dzp + tk_prev / dzm);
         if (i != NLEVSNO - 1) l1 = -onemcn * fact_i * tk_i / dzp;
       }
       if (i == NLEVSNO - 1 && snl > 0) l0 = -onemcn * fact_i * tk_i / (z_nxt - z_cur);
-      st_push_row(w, ld, i, l0, l1, l2, l3, l4, rr);
+      st_push_row(w, sA, sZ, lane, i, l0, l1, l2, l3, l4, rr);
     } else {
       double tk_h2osfc = 0.0;
       if (i == NLEVSNO) {  // calc_h2osfc_tk (:238); the standing-surface-water row: get_rhs_ssw, get_matrix_ssw(_soil)
@@ -291,7 +329,7 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
         const double rw = t_h2osfc + (dtime / c_h2osfc) * (hs_h2osfc - dhsdT * t_h2osfc + ST_CNFAC * fn_h2osfc);
         const double w2 = 1.0 + onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw - (dtime / c_h2osfc) * dhsdT;
         const double w1 = -onemcn * (dtime / c_h2osfc) * tk_h2osfc / dzw;
-        st_push_row(w, ld, NLEVSNO, 0.0, w1, w2, 0.0, 0.0, rw);
+        st_push_row(w, sA, sZ, lane, NLEVSNO, 0.0, w1, w2, 0.0, 0.0, rw);
       }
       // soil rows: get_rhs_soil, get_matrix_soil, get_matrix_soil_snow, get_matrix_soil_ssw
       if (i == NLEVSNO) {
@@ -303,7 +341,7 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
         } else {
           const double dzm = z_cur - z_prev;
           rr = t_cur + fact_i * ((1.0 - frac_sno_eff) * (hs_soil - dhsdT * t_cur) + ST_CNFAC * (fn_i - frac_sno_eff * fn_prev));
-          rr += frac_sno_eff * fact_i * LV(sabg_lyr, NLEVSNO);
+          rr += frac_sno_eff * fact_i * sabg_cur;
           l2 = 1.0 + onemcn * fact_i * (tk_i / dzp + frac_sno_eff * tk_prev / dzm) - (1.0 - frac_sno_eff) * fact_i * dhsdT;
           l1 = -onemcn * fact_i * tk_i / dzp;
           l4 = -frac_sno_eff * onemcn * fact_i * tk_prev / dzm;
@@ -326,51 +364,56 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
         l3 = -onemcn * fact_i * tk_prev / dzm;
         l2 = 1.0 + onemcn * fact_i * tk_prev / dzm;
       }
-      st_push_row(w, ld, i + 1, l0, l1, l2, l3, l4, rr);
+      st_push_row(w, sA, sZ, lane, i + 1, l0, l1, l2, l3, l4, rr);
     }
     z_prev = z_cur;
     z_cur = z_nxt;
     t_cur = t_nxt;
+    zi_cur = zi_nxt;
+    dz_cur = dz_nxt;
+    sabg_cur = sabg_nxt;
     tk_prev = tk_i;
     fn_prev = fn_i;
     thk_cur = thk_nxt;
     cv_cur = cv_nxt;
-    thk_nxt = thk_n2;
-    cv_nxt = cv_n2;
-    z_nxt = z_n2;
-    t_nxt = t_n2;
-    zi_nxt = zi_n2;
+  };
+#pragma unroll 1
+  for (int i = 0; i < NLEVTOT; i += 2) {
+    sweep_level(i, inX);
+    sweep_level(i + 1, inY);
   }
 
   // ---- back substitution (:69-74) and update_temperature (soil_temperature_impl.hh:154-177): row r holds level r for
-  //      the snow layers, standing surface water for r == 5, level r - 1 below; the new temperatures go to the state
-  //      as they appear, the phase-change pass reads them back
+  //      the snow layers, standing surface water for r == 5, level r - 1 below.  The solution of row r replaces Z(r) in
+  //      LDS (rows 19 and 20 - levels 18, 19 - stay in registers); the phase-change pass takes the temperatures from there
+  //      and is the one that writes them to the state.
   double t_soi0, t_ssw;
+  const double x20 = w.Zm1;                    // R(N-1) = Z(N-1)
+  const double x19 = w.Zm2 - w.A19 * x20;      // R(N-2) = Z(N-2) - A(N-2) R(N-1)
   {
-    double r2 = w.Zm1;                   // R(N-1) = Z(N-1)
-    double r1 = w.Zm2 - w.A19 * r2;      // R(N-2) = Z(N-2) - A(N-2) R(N-1)
-    LV(t_soisno, NLEVTOT - 1) = r2;
-    LV(t_soisno, NLEVTOT - 2) = r1;
+    double r2 = x20, r1 = x19;
     t_soi0 = 0.0;
     t_ssw = 0.0;
 #pragma unroll 1
     for (int r = NROW - 3; r >= 0; --r) {
-      const double x = w.Z[(int64_t)r * ld] - w.A[(int64_t)r * ld] * r1 - ((r == NLEVSNO - 1) ? w.B4 : 0.0) * r2;
+      const double x = sZ[r][lane] - sA[r][lane] * r1 - ((r == NLEVSNO - 1) ? w.B4 : 0.0) * r2;
       r2 = r1;
       r1 = x;
-      if (r > NLEVSNO) {
-        LV(t_soisno, r - 1) = x;
-        if (r == NLEVSNO + 1) t_soi0 = x;
-      } else if (r == NLEVSNO) {
-        t_ssw = x;
-      } else if (r >= top) {
-        LV(t_soisno, r) = x;
-      }
+      sZ[r][lane] = x;
+      if (r == NLEVSNO + 1) t_soi0 = x;
+      if (r == NLEVSNO) t_ssw = x;
     }
   }
   t_h2osfc = (frac_h2osfc != 0.0) ? t_ssw : t_soi0;
-  double t_sl1 = LV(t_soisno, NLEVSNO - 1);  // the snow layer next to the ground (new value if active, else unchanged)
+  // the snow layer next to the ground (new value if active, else unchanged)
+  double t_sl1 = (NLEVSNO - 1 >= top) ? sZ[NLEVSNO - 1][lane] : LV(t_soisno, NLEVSNO - 1);
   double ice_sl1 = LV(h2osoi_ice, NLEVSNO - 1);
+  // temperature of level i after the solve (levels >= top)
+#define ST_TNEW(i) ((i) < NLEVSNO ? sZ[(i)][lane] : ((i) < NLEVTOT - 2 ? sZ[(i) + 1][lane] : ((i) == NLEVTOT - 2 ? x19 : x20)))
+
+  // the first two levels of the phase-change pass: in flight across phase_change_h2osfc
+  StPcIn pX = st_load_pc(S, c, ld, 0, top, 0.0);
+  StPcIn pY = st_load_pc(S, c, ld, 1, top, 0.0);
 
   // ---- phase_change_h2osfc (phase_change_impl.hh:11-151)
   double h2osfc = h2osfc0, h2osno = h2osno0, int_snow = S->int_snow[c], snow_depth = S->snow_depth[c];
@@ -470,15 +513,24 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
   // level 4 as phase_change_h2osfc left it (it writes that level even when there is no snow layer)
   LV(t_soisno, NLEVSNO - 1) = t_sl1;
   LV(h2osoi_ice, NLEVSNO - 1) = ice_sl1;
-#pragma unroll 1
-  for (int i = 0; i < NLEVTOT; i++) {
+  // one level; px holds its inputs and is reloaded with those of level i + 2 (two alternating sets, as in the sweep)
+  auto pc_level = [&](const int i, StPcIn& px) __attribute__((always_inline)) {
+    const StPcIn P = px;
+    {
+      const int ip = i + 2;
+      px = st_load_pc(S, c, ld, ip, top, (ip >= NLEVSNO && ip < NLEVTOT) ? ST_TNEW(ip) : 0.0);
+    }
     if (i < top) {
       if (i < NLEVSNO) LV(qflx_snofrz_lyr, i) = 0.0;
-      continue;
+      return;
     }
-    double t = LV(t_soisno, i);
-    double ice = LV(h2osoi_ice, i), liq = LV(h2osoi_liq, i);
-    const double fact_i = LV(fact, i);
+    double t = ST_TNEW(i);
+    double ice = P.ice, liq = P.liq;
+    if (i == NLEVSNO - 1) {  // as phase_change_h2osfc left it
+      t = t_sl1;
+      ice = ice_sl1;
+    }
+    const double fact_i = P.fact;
     int imelt = 0;
     double tinc = 0.0, supercool = 0.0;
     if (i < NLEVSNO) {  // snow (:222-238)
@@ -500,9 +552,8 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
       }
       if (t < TFRZ) {
         const double smp = HFUS * (TFRZ - t) / (GRAV * t) * 1000.0;
-        const int j = i - NLEVSNO;
-        supercool = LV(watsat, j) * elmk_pow(smp / LV(sucsat, j), -1.0 / LV(bsw, j));
-        supercool *= LV(dz, i) * 1000.0;
+        supercool = P.watsat * elmk_pow(smp / P.sucsat, -1.0 / P.bsw);
+        supercool *= P.dz * 1000.0;
       }
       if (liq > supercool && t < TFRZ) {
         imelt = 2;
@@ -546,7 +597,8 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
       imelt = 0;
     }
     double frz = 0.0;
-    if (imelt > 0 && fabs(hm) > 0.0) {
+    const bool moved = imelt > 0 && fabs(hm) > 0.0;
+    if (moved) {
       double xm = hm * dtime / HFUS;
       if (i == NLEVSNO) {
         if (snl == 0 && h2osno > 0.0 && xm > 0.0) {
@@ -616,10 +668,17 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
     }
     LV(imelt, i) = imelt;
     LV(t_soisno, i) = t;
-    LV(h2osoi_ice, i) = ice;
-    LV(h2osoi_liq, i) = liq;
+    if (moved) {  // (a level without phase change keeps the ice and liquid it was read with: nothing to write)
+      LV(h2osoi_ice, i) = ice;
+      LV(h2osoi_liq, i) = liq;
+    }
     if (i == top) t_top_new = t;
     if (i == NLEVSNO) t_soi0 = t;
+  };
+#pragma unroll 1
+  for (int i = 0; i < NLEVTOT; i += 2) {
+    pc_level(i, pX);
+    pc_level(i + 1, pY);
   }
   S->xmf[c] = xmf;
   S->qflx_snofrz[c] = qflx_snofrz;
@@ -655,7 +714,6 @@ __global__ __launch_bounds__(ST_WG, 4) void k_soil_temperature(const DevState* _
 void launch_soil_temperature(const DevState* S, int64_t n, double dt, hipStream_t st)
 {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_st_props, dim3((unsigned)((n + 255) / 256), NLEVTOT), dim3(256), 0, st, S);
   hipLaunchKernelGGL(k_soil_temperature, dim3((unsigned)((n + ST_WG - 1) / ST_WG)), dim3(ST_WG), 0, st, S, dt);
 }
 

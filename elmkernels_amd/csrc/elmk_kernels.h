@@ -21,8 +21,8 @@ struct SideStreams {
 
 // the seven physics launches (one per reference L3 wrapper)
 void launch_frac_wet(const DevState* S, int64_t n, hipStream_t st);
-// reset_lists = false: the caller has zeroed the layer-count lists (the fused step does it in k_fz_prep)
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool reset_lists = true);
+// classify = false: the caller has run stage 1 (soil albedo, SNICAR queues) itself (the fused step does it in k_fz_prep)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify = true);
 void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);

@@ -454,67 +454,75 @@ ELMK_MFN double elmk_pow_general(double x, double y)
 // everything the physics does - log_inline and exp_inline run as one straight-line block; any other argument takes the
 // single branch to the general form afterwards.
 // main path as a branch-free block; `rare` set for every argument pair outside it
-ELMK_MFN double elmk_pow_main_tab(double x, double y, int* rare, const uint64_t* powlog_tab)
-{
-  const uint64_t ix = elmk_asu64(x);
-  const uint32_t topx = (uint32_t)(ix >> 52);
-  const uint32_t topy = (uint32_t)(elmk_asu64(y) >> 52);
-  const int rare_arg = (topx - 0x001u >= 0x7ffu - 0x001u) | ((topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu);
-  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
-  const double A0 = -0x1p-1, A1 = -0x1.555555555556p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
-               A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p0, A6 = 0x1.0002b8b263fc3p0;
-  const uint64_t tmp = ix - 0x3fe6955500000000ull;
-  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
-  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // (int64_t)tmp >> 52, from the high word
-  const uint64_t iz = ix - (tmp & 0xfffull << 52);
-  const double z = elmk_asf64(iz);
-  const double kd = (double)k;
-  const double invc = elmk_asf64(powlog_tab[3 * i]), logc = elmk_asf64(powlog_tab[3 * i + 1]),
-               logctail = elmk_asf64(powlog_tab[3 * i + 2]);
-  const double r = ELMK_FMA(z, invc, -1.0);
-  const double t1 = ELMK_FMA(kd, Ln2hi, logc);
-  const double t2 = t1 + r;
-  const double lo1 = ELMK_FMA(kd, Ln2lo, logctail);
-  const double lo2 = t1 - t2 + r;
-  const double ar = A0 * r;
-  const double ar2 = r * ar;
-  const double ar3 = r * ar2;
-  const double hi = t2 + ar2;
-  const double lo3 = ELMK_FMA(ar, r, -ar2);
-  const double lo4 = t2 - hi + ar2;
-  const double p12 = ELMK_FMA(r, A2, A1);
-  const double p34 = ELMK_FMA(r, A4, A3);
-  double p = ELMK_FMA(r, A6, A5);
-  p = ELMK_FMA(p, ar2, p34);
-  p = ELMK_FMA(ar2, p, p12);
-  double lo = lo1 + lo2;
-  lo = lo + lo3;
-  lo = lo + lo4;
-  lo = ELMK_FMA(p, ar3, lo);
-  const double lhi = hi + lo;
-  const double llo = hi - lhi + lo;
-  const double ehi = y * lhi;
-  double elo = ELMK_FMA(lhi, y, -ehi);
-  elo = ELMK_FMA(y, llo, elo);
-  // exp_inline, main path
-  const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52;
-  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
-  const uint32_t abstop = (uint32_t)(elmk_asu64(ehi) >> 52) & 0x7ff;
-  double ekd = ELMK_FMA(ehi, InvLn2N, Shift);
-  const uint64_t ki = elmk_asu64(ekd);
-  ekd -= Shift;
-  double er = ELMK_FMA(ekd, NegLn2hiN, ehi);
-  er = ELMK_FMA(ekd, NegLn2loN, er);
-  er = elo + er;
-  const uint32_t idx = 2u * (uint32_t)(ki & 127u);
-  const double tail = elmk_asf64(ELMK_T_EXP[idx]);
-  const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45);
-  const double etmp = elmk_exp_poly(er, tail);
-  const double scale = elmk_asf64(sbits);
-  *rare = rare_arg | (abstop - 0x3c9u >= 0x3fu);
+// (a macro so that log_inline's table can be named at compile time: LDS or global, see elmk_pow_literal_base)
+#define ELMK_POW_MAIN_BODY(powlog_tab) \
+  const uint64_t ix = elmk_asu64(x); \
+  const uint32_t topx = (uint32_t)(ix >> 52); \
+  const uint32_t topy = (uint32_t)(elmk_asu64(y) >> 52); \
+  const int rare_arg = (topx - 0x001u >= 0x7ffu - 0x001u) | ((topy & 0x7ffu) - 0x3beu >= 0x43eu - 0x3beu); \
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45; \
+  const double A0 = -0x1p-1, A1 = -0x1.555555555556p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1, \
+               A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p0, A6 = 0x1.0002b8b263fc3p0; \
+  const uint64_t tmp = ix - 0x3fe6955500000000ull; \
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u; \
+  const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20; \
+  const uint64_t iz = ix - (tmp & 0xfffull << 52); \
+  const double z = elmk_asf64(iz); \
+  const double kd = (double)k; \
+  const double invc = elmk_asf64(powlog_tab[3 * i]), logc = elmk_asf64(powlog_tab[3 * i + 1]), \
+               logctail = elmk_asf64(powlog_tab[3 * i + 2]); \
+  const double r = ELMK_FMA(z, invc, -1.0); \
+  const double t1 = ELMK_FMA(kd, Ln2hi, logc); \
+  const double t2 = t1 + r; \
+  const double lo1 = ELMK_FMA(kd, Ln2lo, logctail); \
+  const double lo2 = t1 - t2 + r; \
+  const double ar = A0 * r; \
+  const double ar2 = r * ar; \
+  const double ar3 = r * ar2; \
+  const double hi = t2 + ar2; \
+  const double lo3 = ELMK_FMA(ar, r, -ar2); \
+  const double lo4 = t2 - hi + ar2; \
+  const double p12 = ELMK_FMA(r, A2, A1); \
+  const double p34 = ELMK_FMA(r, A4, A3); \
+  double p = ELMK_FMA(r, A6, A5); \
+  p = ELMK_FMA(p, ar2, p34); \
+  p = ELMK_FMA(ar2, p, p12); \
+  double lo = lo1 + lo2; \
+  lo = lo + lo3; \
+  lo = lo + lo4; \
+  lo = ELMK_FMA(p, ar3, lo); \
+  const double lhi = hi + lo; \
+  const double llo = hi - lhi + lo; \
+  const double ehi = y * lhi; \
+  double elo = ELMK_FMA(lhi, y, -ehi); \
+  elo = ELMK_FMA(y, llo, elo); \
+  /* exp_inline, main path */ \
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, Shift = 0x1.8p52; \
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47; \
+  const uint32_t abstop = (uint32_t)(elmk_asu64(ehi) >> 52) & 0x7ff; \
+  double ekd = ELMK_FMA(ehi, InvLn2N, Shift); \
+  const uint64_t ki = elmk_asu64(ekd); \
+  ekd -= Shift; \
+  double er = ELMK_FMA(ekd, NegLn2hiN, ehi); \
+  er = ELMK_FMA(ekd, NegLn2loN, er); \
+  er = elo + er; \
+  const uint32_t idx = 2u * (uint32_t)(ki & 127u); \
+  const double tail = elmk_asf64(ELMK_T_EXP[idx]); \
+  const uint64_t sbits = ELMK_T_EXP[idx + 1] + (ki << 45); \
+  const double etmp = elmk_exp_poly(er, tail); \
+  const double scale = elmk_asf64(sbits); \
+  *rare = rare_arg | (abstop - 0x3c9u >= 0x3fu); \
   return ELMK_FMA(scale, etmp, scale);
+ELMK_MFN double elmk_pow_main(double x, double y, int* rare)
+{
+  ELMK_POW_MAIN_BODY(ELMK_T_POWLOG)
 }
-ELMK_MFN double elmk_pow_main(double x, double y, int* rare) { return elmk_pow_main_tab(x, y, rare, ELMK_T_POWLOG); }
+// the same block reading log_inline's table from the read-only array in global memory whatever ELMK_MATH_LDS says (see
+// elmk_pow_literal_base)
+ELMK_MFN double elmk_pow_main_gtab(double x, double y, int* rare)
+{
+  ELMK_POW_MAIN_BODY(elmk_powlog_tab)
+}
 ELMK_MFN double elmk_pow(double x, double y)
 {
   int rare;
@@ -528,7 +536,7 @@ ELMK_MFN double elmk_pow(double x, double y)
 ELMK_MFN double elmk_pow_literal_base(const double x, double y)
 {
   int rare;
-  double res = elmk_pow_main_tab(x, y, &rare, elmk_powlog_tab);
+  double res = elmk_pow_main_gtab(x, y, &rare);
   if (__builtin_expect(rare, 0)) res = elmk_pow_general(x, y);
   return res;
 }

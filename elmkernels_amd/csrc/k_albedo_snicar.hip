@@ -24,14 +24,13 @@
 #define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
+#include "elmk_albedo_col.h"
 
 namespace elmk {
 
-#define LV(f, lev) S->f[(int64_t)(lev) * ld + c]
 
 constexpr double SA_MPE = 1.e-06;   // surface_albedo.h:56
 constexpr double SA_EXTKN = 0.30;   // surface_albedo.h:57
-constexpr double SN_MIN_SNW = 1.0e-30;  // snow_snicar.h:27
 constexpr int SN_RDS_MAX_TBL = 1500, SN_RDS_MIN_TBL = 30;
 // exp(-argmax), argmax = 10 (snow_snicar_impl.hh:360): the reference's constexpr value, 0x1.7cd79b5647c9bp-15
 constexpr double SN_EXP_MIN = 4.5399929762484854e-05;
@@ -349,70 +348,6 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
                                            const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
                                            const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha);
 
-// per-column body of stage 1; returns the number of snow layers if the column must go through SNICAR, else 0
-__device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L)
-{
-  const double coszen = S->coszen[c];
-  const double elai = S->elai[c];
-
-  // ---- canopy_layer_lai (:215-319), nlevcan == 1: one big-leaf layer
-  S->nrad[c] = 1;
-  S->tlai_z[c] = elai;
-  // (laisum/saisum of a single layer equal elai/esai exactly: the reference's consistency throw cannot fire)
-
-  if (!(coszen > 0.0)) return -1;  // night column: stage 3 writes the init_timestep defaults
-
-  // =========================== sunlit column ===========================
-  const double h2osno = S->h2osno[c];
-  const int snl = S->snl[c];
-
-  // ---- soil_albedo (:690-754)
-  double albsod[2], albsoi[2];
-  {
-    const double albice[2] = {0.8, 0.55};
-    const double alblak[2] = {0.60, 0.40};
-    const double alblakwi[2] = {0.10, 0.10};
-    if (L.ltype == istsoil || L.ltype == istcrop) {
-      const int col = S->isoicol[c];
-      const double inc = dmax(0.11 - 0.40 * LV(h2osoi_vol, 0), 0.0);
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        albsod[ib] = dmin(S->albsat[col][ib] + inc, S->albdry[col][ib]);
-        albsoi[ib] = albsod[ib];
-      }
-    } else if (L.ltype == istice || L.ltype == istice_mec) {
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        albsod[ib] = albice[ib];
-        albsoi[ib] = albsod[ib];
-      }
-    } else if (L.ltype == istdlak && snl == 0) {
-      const double t_grnd = S->t_grnd[c];
-      const double sicefr = 1.0 - elmk_exp(-95.6 * (TFRZ - t_grnd) / TFRZ);
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        albsod[ib] = sicefr * alblak[ib] + (1.0 - sicefr) * dmax(alblakwi[ib], 0.05 / (dmax(0.001, coszen) + 0.15));
-        albsoi[ib] = sicefr * alblak[ib] + (1.0 - sicefr) * dmax(alblakwi[ib], 0.10);
-      }
-    } else {
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        albsod[ib] = alblak[ib];
-        albsoi[ib] = albsod[ib];
-      }
-    }
-  }
-
-
-  // sunlit: leave the soil albedos for stage 2 and queue the column by its snow-layer count
-  LV(albsod, 0) = albsod[0];
-  LV(albsod, 1) = albsod[1];
-  LV(albsoi, 0) = albsoi[0];
-  LV(albsoi, 1) = albsoi[1];
-  if (h2osno > SN_MIN_SNW) return snl == 0 ? 1 : snl;  // snl == 0: one fictitious fresh-snow layer (flg_nosnl, :42-48)
-  return 0;
-}
-
 // ground_albedo (:155-167), flux_absorption_factor (:171-211, subgridflag == 1) and two_stream_solver (:323-687,
 // nlevcan == 1) for one sunlit column, given soil albedos and the SNICAR products; for a column without sun (day ==
 // false) the values surface_albedo::init_timestep leaves (:90-151) and snow_albedo_radiation_factor's "no sun" branch
@@ -668,9 +603,11 @@ __global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict
 template <int NL>
 __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restrict__ S)
 {
+  const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
+  // nothing in the queue for this workgroup (the whole launch, when no column has NL layers): leave before the table copy
+  if ((uint64_t)blockIdx.x * (blockDim.x >> 6) * 6u >= count) return;
   elmk_math_lds_init<false>();
   const int64_t ld = S->ld;
-  const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
   const gptr<const int32_t> list = S->lists + (int64_t)(LIST_ALB_0 + NL) * ld;
   constexpr int snl_top = NLEVSNO - NL;
   const int lane = threadIdx.x & 63;
@@ -717,6 +654,12 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
   const Land L = S->land;
+  // The layer-count queues have been drained by now: leave them empty for the next classification (they are empty at
+  // context creation and after every call, so neither k_alb_classify nor the fused step's k_fz_prep resets them).
+  if (blockIdx.x == 0 && threadIdx.x < 6) {
+    ELMK_LIST_COUNT(S, LIST_ALB_0 + threadIdx.x) = 0u;
+    ELMK_LIST_HEAD(S, LIST_ALB_0 + threadIdx.x) = 0u;
+  }
   if (L.urbpoi || c >= S->ncols) return;
   const double coszen = S->coszen[c];
   const double elai = S->elai[c];
@@ -769,15 +712,7 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
   alb_finish(S, c, ld, L, day, coszen, elai, esai, frac_sno, albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
 }
 
-__global__ void k_alb_reset(const DevState* __restrict__ S)
-{
-  if (threadIdx.x < 6) {
-    ELMK_LIST_COUNT(S, LIST_ALB_0 + threadIdx.x) = 0u;
-    ELMK_LIST_HEAD(S, LIST_ALB_0 + threadIdx.x) = 0u;
-  }
-}
-
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool reset_lists)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify)
 {
   if (n <= 0) return;
   const dim3 block(256);
@@ -785,21 +720,30 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   // stage 2 is grid-stride over a device-side count: 24 columns per workgroup
   const unsigned want = (unsigned)((n + 23) / 24);
   const unsigned capped = want < 4096u ? want : 4096u;
-  if (reset_lists) hipLaunchKernelGGL(k_alb_reset, dim3(1), dim3(64), 0, st, S);
-  hipLaunchKernelGGL(k_alb_classify, dim3(full), block, 0, st, S);
-  // The five layer-count queues are independent: side streams let their launches overlap (fork/join with events).
-  // (One persistent launch draining all five lists through a chunk counter was measured 30 % slower: every wave then
-  // pays the deepest list's register footprint, and the five unrolled bodies compete for the instruction cache.)
-  (void)hipEventRecord(side->fork, st);
-  for (int i = 0; i < 4; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
-  hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
-  hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, side->s[0], S);
-  hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, side->s[1], S);
-  hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, side->s[2], S);
-  hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, side->s[3], S);
-  for (int i = 0; i < 4; i++) {
-    (void)hipEventRecord(side->join[i], side->s[i]);
-    (void)hipStreamWaitEvent(st, side->join[i], 0);
+  if (classify) hipLaunchKernelGGL(k_alb_classify, dim3(full), block, 0, st, S);
+  // The five layer-count queues are independent.  (One persistent launch draining all five lists through a chunk counter
+  // was measured 30 % slower: every wave then pays the deepest list's register footprint, and the five unrolled bodies
+  // compete for the instruction cache.)  With many columns every non-empty queue fills the GPU by itself and an empty one
+  // costs a few microseconds, so the launches simply follow each other; the fork and join through side streams cost
+  // ~35 us of dependency latency per call and only pay when the queues are too short to fill the machine.
+  if (n >= 262144) {
+    hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);
+    hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, st, S);
+    hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, st, S);
+    hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, st, S);
+    hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, st, S);
+  } else {
+    (void)hipEventRecord(side->fork, st);
+    for (int i = 0; i < 4; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
+    hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
+    hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, side->s[0], S);
+    hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, side->s[1], S);
+    hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, side->s[2], S);
+    hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, side->s[3], S);
+    for (int i = 0; i < 4; i++) {
+      (void)hipEventRecord(side->join[i], side->s[i]);
+      (void)hipStreamWaitEvent(st, side->join[i], 0);
+    }
   }
   hipLaunchKernelGGL(k_alb_final, dim3(full), block, 0, st, S);
 }

@@ -21,6 +21,7 @@
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 #include "elmk_stream.h"
+#include "elmk_albedo_col.h"
 
 namespace elmk {
 
@@ -1455,20 +1456,26 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
 {
   elmk_math_lds_init<false>();  // (frac_wet: one pow per column)
   __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];
+  __shared__ uint32_t a_cnt[5], a_base[5];  // the SNICAR queues by snow-layer count (albedo stage 1)
   for (int i = threadIdx.x; i < CF_COUNT_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x < NLISTS && threadIdx.x != LIST_CF_QUEUE) {  // (the queue's own counters: cf_queue_position)
+  if (threadIdx.x < 5) a_cnt[threadIdx.x] = 0u;
+  // (not the canopy queue's own counters: cf_queue_position; not the SNICAR queues, which this kernel fills and k_alb_final
+  //  leaves empty for the next call)
+  if (blockIdx.x == 0 && threadIdx.x < NLISTS && threadIdx.x != LIST_CF_QUEUE && !(threadIdx.x >= LIST_ALB_0 && threadIdx.x <= LIST_ALB_5)) {
     ELMK_LIST_COUNT(S, threadIdx.x) = 0u;
     ELMK_LIST_HEAD(S, threadIdx.x) = 0u;
   }
   __syncthreads();
   const Land L = S->land;
+  const int64_t ld = S->ld;
   const int lane = threadIdx.x & 63;
   const int64_t tile0 = (int64_t)blockIdx.x * CF_COUNT_TILES;
-#pragma unroll 4
+  uint32_t apack[CF_COUNT_TILES];  // per tile: queue class << 16 | slot inside this workgroup's share of the queue
+#pragma unroll
   for (int t = 0; t < CF_COUNT_TILES; t++) {  // (unrolled: the loads of several tiles are in flight together)
     const int64_t c = (tile0 + t) * 256 + threadIdx.x;
     const bool inside = c < S->ncols;
-    int cls = -1;
+    int cls = -1, acl = -1;
     if (inside) {
       frac_wet_col(S, c, L);
       if (!L.lakpoi && !L.urbpoi && S->frac_veg_nosno[c] != 0) {
@@ -1476,12 +1483,29 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
         cls = cf_class_of(day, S->cf_niter[c] >> 16);
       }
       S->cf_cls[c] = (int8_t)cls;
+      if (!L.urbpoi) {  // stage 1 of albedo (k_alb_classify): soil albedo of the sunlit columns, SNICAR queue class
+        const int nl = alb_main_column(S, c, ld, L);
+        acl = nl >= 1 ? nl - 1 : -1;
+      }
     }
 #pragma unroll
     for (int k = 0; k < CF_NCLS; k++) {
       const unsigned long long m = __ballot(cls == k);
       if (lane == 0 && m) atomicAdd(&s_cnt[t][k], (uint32_t)__popcll(m));
     }
+    uint32_t aoff = 0u;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const unsigned long long m = __ballot(acl == k);
+      if (m != 0ull) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t off = 0u;
+        if (lane == leader) off = atomicAdd(&a_cnt[k], (uint32_t)__popcll(m));
+        off = __shfl(off, leader, 64);
+        if (acl == k) aoff = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      }
+    }
+    apack[t] = acl >= 0 ? ((uint32_t)acl << 16) | aoff : 0xffffffffu;
   }
   __syncthreads();
   if (threadIdx.x < CF_NCLS) {
@@ -1492,6 +1516,18 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
     for (int t = 0; t < CF_COUNT_TILES; t++) {
       if (tile0 + t < S->cf_nblk) S->cf_blk[(int64_t)k * S->cf_nblk + tile0 + t] = base;
       base += s_cnt[t][k];
+    }
+  }
+  if (threadIdx.x < 5) {
+    const uint32_t n = a_cnt[threadIdx.x];
+    a_base[threadIdx.x] = n ? atomicAdd(ELMK_GENERIC(&ELMK_LIST_COUNT(S, LIST_ALB_1 + threadIdx.x)), n) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < CF_COUNT_TILES; t++) {
+    if (apack[t] != 0xffffffffu) {
+      const int k = (int)(apack[t] >> 16);
+      S->lists[(int64_t)(LIST_ALB_1 + k) * ld + a_base[k] + (apack[t] & 0xffffu)] = (int32_t)((tile0 + t) * 256 + threadIdx.x);
     }
   }
 }

@@ -409,7 +409,14 @@ __global__ __launch_bounds__(ST_WG, 2) void k_soil_temperature(const DevState* _
   double t_sl1 = (NLEVSNO - 1 >= top) ? sZ[NLEVSNO - 1][lane] : LV(t_soisno, NLEVSNO - 1);
   double ice_sl1 = LV(h2osoi_ice, NLEVSNO - 1);
   // temperature of level i after the solve (levels >= top)
-#define ST_TNEW(i) ((i) < NLEVSNO ? sZ[(i)][lane] : ((i) < NLEVTOT - 2 ? sZ[(i) + 1][lane] : ((i) == NLEVTOT - 2 ? x19 : x20)))
+  // (one LDS read from a clamped row, then a value select: a select between an LDS row and a register would go through
+  //  a generic pointer)
+  auto st_tnew = [&](const int i) __attribute__((always_inline)) {
+    const int r = i < NLEVSNO ? i : (i < NLEVTOT - 2 ? i + 1 : ST_LDS_ROWS - 1);
+    const double v = sZ[r][lane];
+    return i == NLEVTOT - 2 ? x19 : (i == NLEVTOT - 1 ? x20 : v);
+  };
+#define ST_TNEW(i) st_tnew(i)
 
   // the first two levels of the phase-change pass: in flight across phase_change_h2osfc
   StPcIn pX = st_load_pc(S, c, ld, 0, top, 0.0);

@@ -1452,12 +1452,16 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
 //                one produced from registers: t_soisno[20] and some 45 scalars per column are neither re-read nor waited for
 //   k_bg_flux, k_cf_iterate, k_cf_finish   as in the unfused step
 // =====================================================================================================
+#ifndef FZ_PREP_TILES_N
+#define FZ_PREP_TILES_N 4
+#endif
+constexpr int FZ_PREP_TILES = FZ_PREP_TILES_N;  // tiles of 256 columns per workgroup of k_fz_prep
 __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
 {
   elmk_math_lds_init<false>();  // (frac_wet: one pow per column)
-  __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];
+  __shared__ uint32_t s_cnt[FZ_PREP_TILES][CF_NCLS];
   __shared__ uint32_t a_cnt[5], a_base[5];  // the SNICAR queues by snow-layer count (albedo stage 1)
-  for (int i = threadIdx.x; i < CF_COUNT_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < FZ_PREP_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
   if (threadIdx.x < 5) a_cnt[threadIdx.x] = 0u;
   // (not the canopy queue's own counters: cf_queue_position; not the SNICAR queues, which this kernel fills and k_alb_final
   //  leaves empty for the next call)
@@ -1469,10 +1473,10 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
   const Land L = S->land;
   const int64_t ld = S->ld;
   const int lane = threadIdx.x & 63;
-  const int64_t tile0 = (int64_t)blockIdx.x * CF_COUNT_TILES;
-  uint32_t apack[CF_COUNT_TILES];  // per tile: queue class << 16 | slot inside this workgroup's share of the queue
+  const int64_t tile0 = (int64_t)blockIdx.x * FZ_PREP_TILES;
+  uint32_t apack[FZ_PREP_TILES];  // per tile: queue class << 16 | slot inside this workgroup's share of the queue
 #pragma unroll
-  for (int t = 0; t < CF_COUNT_TILES; t++) {  // (unrolled: the loads of several tiles are in flight together)
+  for (int t = 0; t < FZ_PREP_TILES; t++) {  // (unrolled: the loads of several tiles are in flight together)
     const int64_t c = (tile0 + t) * 256 + threadIdx.x;
     const bool inside = c < S->ncols;
     int cls = -1, acl = -1;
@@ -1511,9 +1515,9 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
   if (threadIdx.x < CF_NCLS) {
     const int k = threadIdx.x;
     uint32_t n = 0u;
-    for (int t = 0; t < CF_COUNT_TILES; t++) n += s_cnt[t][k];
+    for (int t = 0; t < FZ_PREP_TILES; t++) n += s_cnt[t][k];
     uint32_t base = n ? atomicAdd(ELMK_GENERIC(&CF_CLASS_COUNT(S, k)), n) : 0u;
-    for (int t = 0; t < CF_COUNT_TILES; t++) {
+    for (int t = 0; t < FZ_PREP_TILES; t++) {
       if (tile0 + t < S->cf_nblk) S->cf_blk[(int64_t)k * S->cf_nblk + tile0 + t] = base;
       base += s_cnt[t][k];
     }
@@ -1524,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < CF_COUNT_TILES; t++) {
+  for (int t = 0; t < FZ_PREP_TILES; t++) {
     if (apack[t] != 0xffffffffu) {
       const int k = (int)(apack[t] >> 16);
       S->lists[(int64_t)(LIST_ALB_1 + k) * ld + a_base[k] + (apack[t] & 0xffffu)] = (int32_t)((tile0 + t) * 256 + threadIdx.x);
@@ -1574,7 +1578,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
   if (n <= 0) return;
   const unsigned nblk = (unsigned)((n + 255) / 256);
   switch (stage) {
-    case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S); break;
+    case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + FZ_PREP_TILES - 1) / FZ_PREP_TILES), dim3(256), 0, st, S); break;
     case 1: launch_albedo_snicar(S, n, st, side, false); break;
     case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;
     case 3: launch_bareground_list(S, n, st); break;

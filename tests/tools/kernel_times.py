@@ -16,8 +16,17 @@ for tier in tiers:
         D.restore_fields()
         st.timestep7(D, 1800.0)
     D.restore_fields()
-    ms, tot = D.profile_timestep7(1800.0, steps)
-    line = " ".join(f"{n}={m:.3f}" for n, m in zip(st.KERNEL_NAMES, ms))
+    if os.environ.get("KT_FUSED"):  # the fused step's launch groups instead of the seven wrappers
+        for _ in range(4):
+            D.restore_fields()
+            st.timestep7_fused(D, 1800.0)
+        D.restore_fields()
+        ms, tot = D.profile_timestep7_fused(1800.0, steps)
+        names = st.KERNEL_NAMES_FUSED
+    else:
+        ms, tot = D.profile_timestep7(1800.0, steps)
+        names = st.KERNEL_NAMES
+    line = " ".join(f"{n}={m:.3f}" for n, m in zip(names, ms))
     gbs = bench.ALGO_BYTES_STEP * cols / (tot * 1e-3) / 1e9
     print(f"tier {tier} cols {cols}: total {tot:.3f} ms ({cols / tot / 1e3:.1f} M col-steps/s, {gbs:.0f} GB/s algo = {gbs / 80:.1f} % of 8 TB/s) | {line}", flush=True)
     D.close()

@@ -490,7 +490,7 @@ def main(argv=None):
                 "workload": f"soil-column vertical solve (kokkos_soil_temperature: 21-row pentadiagonal system, phase change), {args.cols} columns per GPU, fp64",
                 "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name, "parallelism": par,
             }
-            out["roofline"] = {"bound": "hbm", "kernel": "k_st_* + k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_soil_temperature", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "traffic": pmc_traffic("soil_temperature", args.tier, args.cols, f"{PROFILE_TAG}_hbm_traffic_pmc_soil_tier{args.tier}.json"),
                                "bytes_per_column": SOIL_ALGO_BYTES, "avg_launch_ms": ms_total}

@@ -14,10 +14,16 @@
 //
 // The reference runs these as five parallel_for launches over columns; a column only ever reads what the same column
 // wrote, so here one thread takes its column through all of them in one launch.  The work is layer re-meshing: short
-// data-dependent loops over at most five snow levels whose bounds differ from lane to lane.  Level arrays are addressed
-// in place (SoA [level][column]: a lane's level i of a field is one 8-byte element; the lanes of a wave that are on the
-// same level read one contiguous row), so the code below is the reference's control flow statement for statement; the
-// column's few hundred bytes stay in L1 / L2 between the passes.
+// data-dependent loops over at most five snow levels whose bounds differ from lane to lane, i.e. dynamically indexed
+// level arrays and long chains of dependent accesses to them.  With the arrays addressed in place in global memory
+// (the first version) every link of those chains was a trip to L2: PMC showed the waves waiting 85 % of their cycles and
+// 3.9 KB of HBM traffic per column (intermediate values written out between passes).  Now THE PACK LIVES IN LDS for the
+// duration of the kernel: the 70 rows a column can touch (levels 0..5 of liquid, ice, temperature, thickness and
+// interface depth - level 5 is the top soil layer, which snow_water and combine_layers reach -, levels 0..4 of node
+// depth, grain radius and the six aerosol masses) are loaded as coalesced rows into [row][lane] slices (conflict-free,
+// dynamic indexing costs nothing there), the passes below run on LDS as the reference's control flow statement for
+// statement, and every row is written back once at the end (an unchanged value goes back as the same bits).
+// 70 rows x 64 lanes x 8 B = 35 KB per one-wave workgroup, four workgroups per CU.
 //
 // Where the reference's result is not defined (include/elmk.h, ELMK_WARN_SNOW_*): snow_water's vol_ice[i+i] for i = 3 is
 // out of bounds (vol_ice[i+1] is used); combine_layers' shift loop reads element -1 of the level arrays when the pack has
@@ -36,12 +42,16 @@ constexpr double CPWAT = 4.188e3;    // elm_constants.h:41
 constexpr int NAER = 6;              // bcphi, bcpho, dst1..dst4
 
 // the level arrays of one column
+constexpr int SN_WG = 64;  // one wave per workgroup: no barrier, each lane only touches its own LDS slices
+typedef __attribute__((address_space(3))) double* lds_f64;
 struct SnowCol {
-  int64_t ld;
-  gptr<double> liq, ice, t, dz, z, zi, rds;
-  gptr<double> m[NAER];
+  lds_f64 liq, ice, t, dz, z, zi, rds;
+  lds_f64 m[NAER];
 };
-#define AT(p, i) (p)[(int64_t)(i) * K.ld]
+#define AT(p, i) (p)[(i) * SN_WG]
+// rows of the LDS pack: six levels for the arrays that are reached at the top soil layer, five for the others
+constexpr int SN_ROW_LIQ = 0, SN_ROW_ICE = 6, SN_ROW_T = 12, SN_ROW_DZ = 18, SN_ROW_ZI = 24, SN_ROW_Z = 30, SN_ROW_RDS = 35,
+              SN_ROW_M = 40, SN_ROWS = 70;
 
 // static_cast<int>(std::round(x)) as x86-64 evaluates it (cvttsd2si): INT_MIN for NaN and out-of-range values
 __device__ __forceinline__ int round_to_int(double x)
@@ -176,7 +186,7 @@ __device__ __forceinline__ void snow_compaction(const DevState* __restrict__ S, 
                                                 const double n_melt, const double frac_sno)
 {
   const double c2 = 23.e-3, c3 = 2.777e-6, c4 = 0.04, c5 = 2.0, dm = 100.0, eta0 = 9.0e+5;
-  const int64_t ld = K.ld;
+  const int64_t ld = S->ld;
   const int top = NLEVSNO - snl;
   double burden = 0.0;
   for (int i = top; i < NLEVSNO; ++i) {
@@ -518,7 +528,7 @@ __device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const
 {
   const double snw_rds_refrz = 1000.0;
   const double C2_liq_Brun89 = 4.22e-13;
-  const int64_t ld = K.ld;
+  const int64_t ld = S->ld;
   if (snl > 0) {
     const int snl_btm = NLEVSNO - 1;
     const int snl_top = NLEVSNO - snl;
@@ -600,37 +610,61 @@ __device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_snow_hydrology(const DevState* __restrict__ S, const double dtime)
+__global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __restrict__ S, const double dtime)
 {
+  __shared__ double s_pack[SN_ROWS][SN_WG];
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= S->ncols) return;
   const int64_t ld = S->ld;
   const Land L = S->land;
+  const int lane = (int)threadIdx.x;
+  // the pack: global rows -> LDS (all loads independent: one batch in flight)
+  const gptr<double> g6[5] = {S->h2osoi_liq + c, S->h2osoi_ice + c, S->t_soisno + c, S->dz + c, S->zisoi + c};
+  const gptr<double> g5[2 + NAER] = {S->zsoi + c, S->snw_rds + c, S->mss_bcphi + c, S->mss_bcpho + c,
+                                     S->mss_dst1 + c, S->mss_dst2 + c, S->mss_dst3 + c, S->mss_dst4 + c};
+#pragma unroll
+  for (int f = 0; f < 5; f++)
+#pragma unroll
+    for (int i = 0; i < 6; i++) s_pack[f * 6 + i][lane] = g6[f][(int64_t)i * ld];
+#pragma unroll
+  for (int f = 0; f < 2 + NAER; f++)
+#pragma unroll
+    for (int i = 0; i < 5; i++) s_pack[SN_ROW_Z + f * 5 + i][lane] = g5[f][(int64_t)i * ld];
   SnowCol K;
-  K.ld = ld;
-  K.liq = S->h2osoi_liq + c;
-  K.ice = S->h2osoi_ice + c;
-  K.t = S->t_soisno + c;
-  K.dz = S->dz + c;
-  K.z = S->zsoi + c;
-  K.zi = S->zisoi + c;
-  K.rds = S->snw_rds + c;
-  K.m[0] = S->mss_bcphi + c;
-  K.m[1] = S->mss_bcpho + c;
-  K.m[2] = S->mss_dst1 + c;
-  K.m[3] = S->mss_dst2 + c;
-  K.m[4] = S->mss_dst3 + c;
-  K.m[5] = S->mss_dst4 + c;
+  K.liq = (lds_f64)&s_pack[SN_ROW_LIQ][lane];
+  K.ice = (lds_f64)&s_pack[SN_ROW_ICE][lane];
+  K.t = (lds_f64)&s_pack[SN_ROW_T][lane];
+  K.dz = (lds_f64)&s_pack[SN_ROW_DZ][lane];
+  K.zi = (lds_f64)&s_pack[SN_ROW_ZI][lane];
+  K.z = (lds_f64)&s_pack[SN_ROW_Z][lane];
+  K.rds = (lds_f64)&s_pack[SN_ROW_RDS][lane];
+#pragma unroll
+  for (int a = 0; a < NAER; a++) K.m[a] = (lds_f64)&s_pack[SN_ROW_M + a * 5][lane];
   uint32_t err = 0;
 
+  // every per-column scalar of the wrapper, read here beside the pack (the compiler cannot move a load above the stores
+  // of an earlier pass, and with one wave per SIMD a load issued where it is used is a stall)
   int snl = S->snl[c];
   const int do_capsnow = S->do_capsnow[c];
   double frac_sno_eff = S->frac_sno_eff[c], frac_sno = S->frac_sno[c], h2osno = S->h2osno[c], int_snow = S->int_snow[c];
   const double qflx_sub_snow = S->qflx_sub_snow[c];
   double qflx_snow_melt = S->qflx_snow_melt[c], qflx_top_soil = S->qflx_top_soil[c], mflx_neg_snow;
+  const double qflx_evap_grnd = S->qflx_evap_grnd[c], qflx_dew_snow = S->qflx_dew_snow[c], qflx_dew_grnd = S->qflx_dew_grnd[c],
+               qflx_rain_grnd = S->qflx_rain_grnd[c], qflx_snomelt = S->qflx_snomelt[c];
+  const double dep0 = S->aer_bcphi[c], dep1a = S->aer_bcpho[c], dep1b = S->aer_bcdep[c], dep2a = S->aer_dst1_1[c],
+               dep2b = S->aer_dst1_2[c], dep3a = S->aer_dst2_1[c], dep3b = S->aer_dst2_2[c], dep4a = S->aer_dst3_1[c],
+               dep4b = S->aer_dst3_2[c], dep5a = S->aer_dst4_1[c], dep5b = S->aer_dst4_2[c];
+  const bool veg_active = S->veg_active[c] != 0;
+  const double qflx_tran_veg = S->qflx_tran_veg[c];
+  double rootr[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) rootr[i] = S->rootr[(int64_t)i * ld + c];
+  const double n_melt = S->n_melt[c];
+  double snow_depth = S->snow_depth[c];
+  const double qflx_snwcp_ice = S->qflx_snwcp_ice[c], qflx_snow_grnd = S->qflx_snow_grnd[c];
 
-  snow_water(K, do_capsnow, snl, dtime, frac_sno_eff, h2osno, qflx_sub_snow, S->qflx_evap_grnd[c], S->qflx_dew_snow[c],
-             S->qflx_dew_grnd[c], S->qflx_rain_grnd[c], S->qflx_snomelt[c], qflx_snow_melt, qflx_top_soil, int_snow, frac_sno,
+  snow_water(K, do_capsnow, snl, dtime, frac_sno_eff, h2osno, qflx_sub_snow, qflx_evap_grnd, qflx_dew_snow,
+             qflx_dew_grnd, qflx_rain_grnd, qflx_snomelt, qflx_snow_melt, qflx_top_soil, int_snow, frac_sno,
              mflx_neg_snow, err);
   S->qflx_snow_melt[c] = qflx_snow_melt;
   S->qflx_top_soil[c] = qflx_top_soil;
@@ -639,12 +673,12 @@ __global__ __launch_bounds__(256) void k_snow_hydrology(const DevState* __restri
   // compute_aerosol_deposition (aerosol_physics_impl.hh:36-64): the top snow layer receives the deposition of the step
   if (snl > 0) {
     const int j = NLEVSNO - snl;
-    AT(K.m[0], j) += (S->aer_bcphi[c] * dtime);
-    AT(K.m[1], j) += ((S->aer_bcpho[c] + S->aer_bcdep[c]) * dtime);
-    AT(K.m[2], j) += ((S->aer_dst1_1[c] + S->aer_dst1_2[c]) * dtime);
-    AT(K.m[3], j) += ((S->aer_dst2_1[c] + S->aer_dst2_2[c]) * dtime);
-    AT(K.m[4], j) += ((S->aer_dst3_1[c] + S->aer_dst3_2[c]) * dtime);
-    AT(K.m[5], j) += ((S->aer_dst4_1[c] + S->aer_dst4_2[c]) * dtime);
+    AT(K.m[0], j) += (dep0 * dtime);
+    AT(K.m[1], j) += ((dep1a + dep1b) * dtime);
+    AT(K.m[2], j) += ((dep2a + dep2b) * dtime);
+    AT(K.m[3], j) += ((dep3a + dep3b) * dtime);
+    AT(K.m[4], j) += ((dep4a + dep4b) * dtime);
+    AT(K.m[5], j) += ((dep5a + dep5b) * dtime);
   }
 
   // aerosol_phase_change (:502-548): sublimation moves within-ice black carbon to the external state, top layer only
@@ -670,15 +704,13 @@ __global__ __launch_bounds__(256) void k_snow_hydrology(const DevState* __restri
   }
 
   // transpiration (transpiration_impl.hh:15-28; nlevsoi = 10)
-  if (S->veg_active[c]) {
-    const double qflx_tran_veg = S->qflx_tran_veg[c];
+  if (veg_active) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) S->qflx_rootsoi[(int64_t)i * ld + c] = S->rootr[(int64_t)i * ld + c] * qflx_tran_veg;
+    for (int i = 0; i < 10; ++i) S->qflx_rootsoi[(int64_t)i * ld + c] = rootr[i] * qflx_tran_veg;
   }
 
-  snow_compaction(S, K, c, snl, L.ltype, dtime, int_snow, S->n_melt[c], frac_sno);
+  snow_compaction(S, K, c, snl, L.ltype, dtime, int_snow, n_melt, frac_sno);
 
-  double snow_depth = S->snow_depth[c];
   double qflx_sl_top_soil, qflx_snow2topsoi, mflx_snowlyr_col;
   combine_layers(K, L.urbpoi != 0, L.ltype, dtime, snl, h2osno, snow_depth, frac_sno_eff, frac_sno, int_snow, qflx_sl_top_soil,
                  qflx_snow2topsoi, mflx_snowlyr_col, err);
@@ -712,7 +744,6 @@ __global__ __launch_bounds__(256) void k_snow_hydrology(const DevState* __restri
   // update_aerosol_mass_and_concen (aerosol_physics_impl.hh:10-31, :67-106)
   {
     const int snotop = NLEVSNO - snl;
-    const double qflx_snwcp_ice = S->qflx_snwcp_ice[c];
     const gptr<double> cnc[NAER] = {S->cnc_bcphi + c, S->cnc_bcpho + c, S->cnc_dst1 + c, S->cnc_dst2 + c, S->cnc_dst3 + c, S->cnc_dst4 + c};
 #pragma unroll
     for (int sl = 0; sl < NLEVSNO; sl++) {
@@ -723,18 +754,28 @@ __global__ __launch_bounds__(256) void k_snow_hydrology(const DevState* __restri
       for (int a = 0; a < NAER; a++) {
         const double m = AT(K.m[a], sl) * scl;
         AT(K.m[a], sl) = m;
-        AT(cnc[a], sl) = m * snwmss_inv;
+        cnc[a][(int64_t)sl * ld] = m * snwmss_inv;
       }
     }
   }
 
-  snow_aging(S, K, c, do_capsnow, snl, frac_sno, dtime, S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c], h2osno, err);
+  snow_aging(S, K, c, do_capsnow, snl, frac_sno, dtime, qflx_snwcp_ice, qflx_snow_grnd, h2osno, err);
   if (err) S->err_flags[c] |= err;
+  // the pack: LDS -> global rows.  Of level 5 only liquid and ice can have changed; temperature, thickness and interface
+  // depth of the top soil layer are read-only here.
+#pragma unroll
+  for (int f = 0; f < 5; f++)
+#pragma unroll
+    for (int i = 0; i < (f < 2 ? 6 : 5); i++) g6[f][(int64_t)i * ld] = s_pack[f * 6 + i][lane];
+#pragma unroll
+  for (int f = 0; f < 2 + NAER; f++)
+#pragma unroll
+    for (int i = 0; i < 5; i++) g5[f][(int64_t)i * ld] = s_pack[SN_ROW_Z + f * 5 + i][lane];
 }
 
 void launch_snow_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_snow_hydrology, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dt);
+  if (n > 0) hipLaunchKernelGGL(k_snow_hydrology, dim3((unsigned)((n + SN_WG - 1) / SN_WG)), dim3(SN_WG), 0, st, S, dt);
 }
 
 }  // namespace elmk

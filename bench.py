@@ -407,6 +407,17 @@ def main(argv=None):
                 "frac_of_fused_bound": ALGO_BYTES_FUSED * n / (totf * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "launch_groups_ms": {k: round(m, 4) for k, m in zip(st.KERNEL_NAMES_FUSED, msf)}}
 
+    def advance_too(D, n):
+        """The whole device part of ELMInterface::advance as one call (elmk_advance_physics: the fused seven, soil_temperature,
+        snow_hydrology, surface_fluxes): mean device time per step by HIP events, with the same restores between steps as the
+        seven-wrapper step.  Reported beside that step - BASELINE's metric is defined on the seven - never instead of it."""
+        from elmkernels_amd import synth
+
+        D.set_snow_age_tables(synth.snow_age_tables())
+        D.profile_wrapper(st.WRAPPER_NAMES.index("advance_physics"), 1800.0, 5)  # (warm-up: scheduling hints, first-step transients)
+        ms = D.profile_wrapper(st.WRAPPER_NAMES.index("advance_physics"), 1800.0, 5)
+        return {"ms_per_step_events": round(ms, 4), "value": n / (ms * 1e-3)}
+
     D, host_state = prepared(args.tier)
     # population of the predicate-gated wrappers (SURVEY 8(d): "active-bytes" variant of the roofline numerator)
     veg_frac = float((D["frac_veg_nosno"] != 0).mean())
@@ -419,8 +430,12 @@ def main(argv=None):
     names = [] if rehearsal is not None else (st.KERNEL_NAMES_FUSED if args.fused else st.KERNEL_NAMES)
     also_fused = rank == 0 and world == 1 and rehearsal is None and not args.fused and not (args.workload == "soil_temperature")
     fused_step = None
+    advance_step = None
     if also_fused:
         fused_step = {"bytes_per_column_step": ALGO_BYTES_FUSED, TIER_NAMES[args.tier]: fused_too(D, ncols, args.steps, args.warmup)}
+        if args.cols <= 2_000_000:
+            advance_step = {"what": "elmk_advance_physics: the seven (fused) + soil_temperature + snow_hydrology + surface_fluxes, one call",
+                            TIER_NAMES[args.tier]: advance_too(D, ncols)}
 
     other = None
     north = None
@@ -437,6 +452,8 @@ def main(argv=None):
                  "ms_per_step_events": tot2}
         if also_fused:
             fused_step[TIER_NAMES[ot]] = fused_too(D2, ncols, args.steps, args.warmup)
+            if advance_step is not None:
+                advance_step[TIER_NAMES[ot]] = advance_too(D2, ncols)
         D2.close()
     if solo and not args.no_north_star and not soil and args.cols < NORTH_STAR_COLS:
         # the north-star size in the same run: 10 M columns (64 GB of state + scratch), 5 timed steps per tier
@@ -543,6 +560,8 @@ def main(argv=None):
             out["other_tier"] = other
         if fused_step is not None:
             out["fused_step"] = fused_step
+        if advance_step is not None:
+            out["advance_step"] = advance_step
         if north is not None:
             out["north_star_10M"] = north
         if not args.no_cpu_baseline and world == 1 and rehearsal is None:  # reported at N = 1 only

@@ -25,4 +25,7 @@ from .state import (  # noqa: F401
     kokkos_frac_wet,
     kokkos_surface_radiation,
     timestep7,
+    timestep7_fused,
+    advance_physics,
+    kokkos_snow_hydrology,
 )

@@ -49,6 +49,7 @@ SIGNATURES = {
     "elmk_bareground_fluxes_given": (C.c_int, [_P, _P]),
     "elmk_timestep7": (C.c_int, [_P, C.c_double]),
     "elmk_timestep7_fused": (C.c_int, [_P, C.c_double]),
+    "elmk_advance_physics": (C.c_int, [_P, C.c_double]),
     "elmk_profile_timestep7_fused": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_soil_temperature": (C.c_int, [_P, C.c_double]),
     "elmk_snow_hydrology": (C.c_int, [_P, C.c_double]),

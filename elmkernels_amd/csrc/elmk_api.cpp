@@ -74,7 +74,7 @@ struct elmk_ctx {
   // elmk_set_graph: the seven wrappers of elmk_timestep7 captured once as a HIP graph (kernel nodes + the side-stream
   // fork / join of albedo_snicar) and replayed; key = (dt, stream)
   bool use_graph = false;
-  GraphSlot graph[2];  // [0] elmk_timestep7, [1] elmk_timestep7_fused
+  GraphSlot graph[3];  // [0] elmk_timestep7, [1] elmk_timestep7_fused, [2] elmk_advance_physics
   std::string err;
 };
 
@@ -882,6 +882,30 @@ int elmk_timestep7_fused(elmk_ctx* ctx, double dt)
   return enqueue_stages(ctx, launch_stage_fused, ELMK_FUSED_NSTAGE, dt, nullptr);
 }
 
+namespace {
+// elmk_advance_physics: the fused seven, then the rest of ELMInterface::advance's per-column calls in its order
+constexpr int ADV_NSTAGE = ELMK_FUSED_NSTAGE + 3;
+void launch_stage_advance(elmk_ctx* ctx, int k, double dt)
+{
+  if (k < ELMK_FUSED_NSTAGE) {
+    launch_stage_fused(ctx, k, dt);
+    return;
+  }
+  switch (k - ELMK_FUSED_NSTAGE) {
+    case 0: launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream); break;
+    case 1: launch_snow_hydrology(ctx->d, ctx->ncols, dt, ctx->stream); break;
+    default: launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
+  }
+}
+}  // namespace
+
+int elmk_advance_physics(elmk_ctx* ctx, double dt)
+{
+  PHYSICS_PROLOGUE();
+  if (ctx->use_graph) return run_graph(ctx, ctx->graph[2], launch_stage_advance, ADV_NSTAGE, dt);
+  return enqueue_stages(ctx, launch_stage_advance, ADV_NSTAGE, dt, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------------------
@@ -929,6 +953,8 @@ void launch_one_wrapper(elmk_ctx* ctx, int wrapper, double dt)
     launch_soil_temperature(ctx->d, ctx->ncols, dt, ctx->stream);
   else if (wrapper == ELMK_WRAPPER_SNOW_HYDROLOGY)
     launch_snow_hydrology(ctx->d, ctx->ncols, dt, ctx->stream);
+  else if (wrapper == ELMK_WRAPPER_ADVANCE_PHYSICS)
+    for (int k = 0; k < ADV_NSTAGE; k++) launch_stage_advance(ctx, k, dt);
   else
     launch_surface_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
 }
@@ -938,7 +964,7 @@ int elmk_profile_wrapper(elmk_ctx* ctx, int wrapper, double dt, int nsteps, floa
 {
   PHYSICS_PROLOGUE();
   if (nsteps <= 0 || !ms_mean) return invalid(ctx, "elmk_profile_wrapper: bad arguments");
-  if (wrapper < 0 || wrapper > ELMK_WRAPPER_SNOW_HYDROLOGY) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
+  if (wrapper < 0 || wrapper > ELMK_WRAPPER_ADVANCE_PHYSICS) return invalid(ctx, "elmk_profile_wrapper: unknown wrapper");
   EventList ev;
   HIPCHK(ev.create((size_t)nsteps * 2));
   for (int s = 0; s < nsteps; s++) {

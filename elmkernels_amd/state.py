@@ -256,7 +256,7 @@ class ELMState:
 
 MATH_FNS = ["exp", "log", "log10", "atan", "sqrt", "tanh", "cos", "erf", "acos", "expm1", "div", "pow"]
 WRAPPER_NAMES = ["frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
-                 "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes", "snow_hydrology"]
+                 "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes", "snow_hydrology", "advance_physics"]
 KERNEL_NAMES = [
     "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
     "bareground_fluxes", "canopy_fluxes",
@@ -371,6 +371,13 @@ def timestep7_fused(S, dt):
     """The same seven calls with the streaming wrappers between albedo and the leaf-temperature iteration fused into one
     pass per column (elmk_timestep7_fused); bit-identical results."""
     S._chk(S.lib.elmk_timestep7_fused(S.ctx, float(dt)), "timestep7_fused")
+
+
+def advance_physics(S, dt):
+    """Every per-column call of ELMInterface::advance after kokkos_init_timestep, in its order
+    (elm_kokkos_interface.cc:289-316): the seven wrappers (fused), soil_temperature, snow_hydrology, surface_fluxes - one
+    call (elmk_advance_physics), one HIP graph launch per step with set_graph(True).  Same bits as the ten calls."""
+    S._chk(S.lib.elmk_advance_physics(S.ctx, float(dt)), "advance_physics")
 
 
 def timestep7(S, dt):

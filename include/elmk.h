@@ -26,6 +26,7 @@
  *   kokkos_bareground_fluxes(S)     bareground_fluxes_kokkos.hh       elmk_bareground_fluxes
  *   kokkos_canopy_fluxes(S,dt)      canopy_fluxes_kokkos.hh           elmk_canopy_fluxes
  *   advance(): the 7 calls in order elm_kokkos_interface.cc:289-307   elmk_timestep7, elmk_timestep7_fused
+ *   advance(): all per-column calls elm_kokkos_interface.cc:289-316   elmk_advance_physics
  *   get_forcing(S, dt, date)        atm_forcing_kokkos.cc:47-75       elmk_get_forcing
  *   update_phenology: ComputePhenology  phenology_kokkos.cc:59-62     elmk_phenology
  *   kokkos_init_timestep's kernel   init_timestep_kokkos.cc:55-75     elmk_init_timestep
@@ -262,6 +263,12 @@ int elmk_phenology(elmk_ctx *ctx, double wt1, double wt2);
  * run all-reduces with MIN / MAX / SUM (the reference's min_max_sum, src/utils/min_max_sum.hh:57-66) - and
  * per_column (may be NULL) the values themselves, [8][ncols].  Synchronises. */
 int elmk_evaluate_conservation(elmk_ctx *ctx, double dt, double *min_max_sum, double *per_column);
+/* Everything ELMInterface::advance calls per column after kokkos_init_timestep, in its order
+ * (elm_kokkos_interface.cc:289-316): the seven wrappers (as elmk_timestep7_fused), kokkos_soil_temperature,
+ * kokkos_snow_hydrology, kokkos_surface_fluxes - one call, and with elmk_set_graph one HIP graph launch per model step.
+ * Same bits as the ten calls.  elmk_set_snow_age_tables must have been called.  (kokkos_evaluate_conservation returns
+ * values to the host and stays a call of its own.) */
+int elmk_advance_physics(elmk_ctx *ctx, double dt);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* OR of all columns' flag words and the first column with a fatal bit (-1 if none); synchronises */
@@ -282,7 +289,8 @@ int elmk_profile_timestep7_fused(elmk_ctx *ctx, double dt, int nsteps, float *ms
 typedef enum {
   ELMK_WRAPPER_FRAC_WET = 0, ELMK_WRAPPER_ALBEDO_SNICAR, ELMK_WRAPPER_CANOPY_HYDROLOGY, ELMK_WRAPPER_SURFACE_RADIATION,
   ELMK_WRAPPER_CANOPY_TEMPERATURE, ELMK_WRAPPER_BAREGROUND_FLUXES, ELMK_WRAPPER_CANOPY_FLUXES,
-  ELMK_WRAPPER_SOIL_TEMPERATURE, ELMK_WRAPPER_SURFACE_FLUXES, ELMK_WRAPPER_SNOW_HYDROLOGY
+  ELMK_WRAPPER_SOIL_TEMPERATURE, ELMK_WRAPPER_SURFACE_FLUXES, ELMK_WRAPPER_SNOW_HYDROLOGY,
+  ELMK_WRAPPER_ADVANCE_PHYSICS /* elmk_advance_physics: all ten in the reference's order */
 } elmk_wrapper;
 int elmk_profile_wrapper(elmk_ctx *ctx, int wrapper, double dt, int nsteps, float *ms_mean);
 /* Read back context-owned scratch (diagnostics; not part of the state contract).

@@ -23,6 +23,7 @@ int drive_one_step(int64_t ncols, const double *t_soisno_cols /* [ncols][20], th
   if (rc == ELMK_OK) rc = elmk_soil_temperature(ctx, dt);
   if (rc == ELMK_OK) rc = elmk_snow_hydrology(ctx, dt);
   if (rc == ELMK_OK) rc = elmk_surface_fluxes(ctx, dt);
+  if (rc == ELMK_OK) rc = elmk_advance_physics(ctx, dt);
   if (rc == ELMK_OK) rc = elmk_error_summary(ctx, &flags, &first_bad);
   if (rc == ELMK_OK && (flags & ELMK_ERR_FATAL_MASK)) fprintf(stderr, "column %ld raised %#x\n", (long)first_bad, (unsigned)flags);
   (void)elmk_destroy(ctx);

@@ -149,7 +149,8 @@ def test_snow_hydrology_other_land_units():
 
 def test_advance_chain_with_snow_hydrology():
     """The reference's whole advance() order (elm_kokkos_interface.cc:278-318) - init_timestep, the seven wrappers,
-    soil_temperature, snow_hydrology, surface_fluxes - chained for twelve steps with no re-synchronisation: the snow pack
+    soil_temperature, snow_hydrology, surface_fluxes (per wrapper, with the fused seven, or as the single call
+    elmk_advance_physics, plain and as a replayed HIP graph) - chained for twelve steps with no re-synchronisation: the snow pack
     is re-meshed on the device step after step (layers appear, merge, split, vanish) and every field stays bit-identical
     to the oracle chain.  The forcing heights are put back before each step, as the driver does (atm_physics_impl.hh:197-203)."""
     n = 6016
@@ -162,19 +163,106 @@ def test_advance_chain_with_snow_hydrology():
             S[k][...] = v
         st.kokkos_init_timestep(D)
         S.init_timestep()
-        (st.timestep7_fused if step % 2 else st.timestep7)(D, DT)
+        if step % 3 == 2:  # the whole device part of advance() as one call; as one replayed HIP graph in the second half
+            D.set_graph(step >= 6)
+            st.advance_physics(D, DT)
+            D.set_graph(False)
+        else:
+            (st.timestep7_fused if step % 2 else st.timestep7)(D, DT)
+            st.kokkos_soil_temperature(D, DT)
+            st.kokkos_snow_hydrology(D, DT)
+            st.kokkos_surface_fluxes(D, DT)
         S.timestep7(DT)
-        st.kokkos_soil_temperature(D, DT)
         S.soil_temperature(DT)
-        st.kokkos_snow_hydrology(D, DT)
         S.snow_hydrology(DT)
-        st.kokkos_surface_fluxes(D, DT)
         S.surface_fluxes(DT)
         _check(D, S, f"advance chain with snow hydrology, step {step}", bitwise=True)
         snl_hist.append(S["snl"].copy())
     changed = sum(int((a != b).sum()) for a, b in zip(snl_hist, snl_hist[1:]))
     assert changed > 50  # the mesh really moved between steps
     D.close()
+
+
+
+def test_cpp_interface_mirror(tmp_path):
+    """include/elmk_interface.hpp - the C++ mirror of the reference's driver class ELM::ELMInterface (setup, advance,
+    getPrimaryVars; elm_kokkos_interface.cc:38-358) - compiled with g++ against libelmk and run as the reference's driver
+    loop (examples/elm_interface_demo.cc): three advance() steps (phenology, forcing, init_timestep, the ten physics calls
+    as one HIP graph, conservation) give the oracle chain's PrimaryVars and conservation diagnostics bit for bit."""
+    import shutil
+    import struct
+    import subprocess
+
+    from elmkernels_amd import _lib as L
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    n, nsteps = 3008, 3
+    D, S = _pair(n, "B", 33)
+    D.close()
+    exe = tmp_path / "demo"
+    import os
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "elm_interface_demo.cc"), "-L" + libdir, "-lelmk",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    rng = np.random.default_rng(3)
+    e = rng.random(8)
+    wt1, wt2 = 1.0 - e, e
+    blob = [struct.pack("<q", n)]
+
+    def rec(name, kind, arr):
+        a = np.ascontiguousarray(arr)
+        blob.append(name.encode().ljust(32, b"\0") + struct.pack("<iq", kind, a.nbytes) + a.tobytes())
+
+    for k, v in S.fields.items():
+        if k != "err_flags":
+            rec(k, 0, v)
+    sc = S.scalars
+    rec("land", 1, np.array([sc["ltype"], sc["ctype"], sc["vtype"], sc["urbpoi"], sc["lakpoi"]], np.int32))
+    rec("scalars", 1, np.array([sc["dewmx"], sc["oldfflag"], sc["dayl"], sc["max_dayl"], DT], np.float64))
+    rec("pft_psn", 1, S.pft_psn)
+    rec("pft_alb", 1, S.pft_alb)
+    rec("z0mr", 1, S.z0mr)
+    rec("displar", 1, S.displar)
+    rec("albsat", 1, S.albsat)
+    rec("albdry", 1, S.albdry)
+    for i, name in enumerate(L.SNICAR_NAMES):
+        rec(f"snicar/{i}", 1, S.snicar[name])
+    rec("age_tau", 1, S.snowage[0])
+    rec("age_kappa", 1, S.snowage[1])
+    rec("age_drdt0", 1, S.snowage[2])
+    rec("forc_wt1", 1, wt1)
+    rec("forc_wt2", 1, wt2)
+    rec("month_wt", 1, np.array([0.3, 0.7]))
+    (tmp_path / "state.bin").write_bytes(b"".join(blob))
+    out = subprocess.run([str(exe), str(tmp_path / "state.bin"), str(nsteps), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for _ in range(nsteps):
+        S.phenology(0.3, 0.7)
+        S.get_forcing(wt1, wt2, False)
+        S.init_timestep()
+        S.timestep7(DT)
+        S.soil_temperature(DT)
+        S.snow_hydrology(DT)
+        S.surface_fluxes(DT)
+        diag = S.evaluate_conservation(DT)
+    raw = (tmp_path / "out.bin").read_bytes()
+    off = 0
+
+    def same_bits(a, b):
+        return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+    for name, dt_, count in (("t_soisno", np.float64, n * 20), ("h2osoi_liq", np.float64, n * 20), ("h2osoi_ice", np.float64, n * 20),
+                             ("t_grnd", np.float64, n), ("h2osno", np.float64, n), ("snl", np.int32, n)):
+        got = np.frombuffer(raw, dt_, count, off).reshape(S[name].shape)
+        off += got.nbytes
+        assert same_bits(got, S[name]), name
+    got = np.frombuffer(raw, np.float64, 24, off).reshape(8, 3)
+    assert same_bits(got[:, 0], diag.min(axis=0)) and same_bits(got[:, 1], diag.max(axis=0))
+    np.testing.assert_allclose(got[:, 2], diag.sum(axis=0), rtol=1e-9, atol=1e-6)  # (sums: association order)
 
 
 def test_other_land_units():

@@ -129,3 +129,22 @@ def test_header_is_plain_c99():
     src = open(os.path.join(ROOT, "tests", "c", "abi_consumer.c")).read()
     for name in ("elmk_create", "elmk_upload", "elmk_timestep7", "elmk_soil_temperature", "elmk_error_summary", "elmk_destroy"):
         assert name in src
+
+
+def test_cpp_interface_mirror_compiles_and_links():
+    """include/elmk_interface.hpp (the C++ mirror of ELM::ELMInterface above the C ABI) and the driver loop that uses it
+    (examples/elm_interface_demo.cc) compile with -Wall -Wextra -Werror and link against libelmk; the class has the
+    reference's member functions (elm_kokkos_interface.hh:16-20).  Nothing is run here (no GPU)."""
+    import subprocess
+    import tempfile
+
+    from elmkernels_amd import _lib as L
+
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "elm_interface_demo.cc"), "-L" + os.path.dirname(L.LIB_PATH), "-lelmk",
+                            "-o", os.path.join(d, "demo")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+    hdr = open(os.path.join(ROOT, "include", "elmk_interface.hpp")).read()
+    for member in ("void setup(", "bool advance(", "void copyPrimaryVars(", "getPrimaryVars()"):
+        assert member in hdr, member

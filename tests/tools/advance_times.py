@@ -28,4 +28,13 @@ for name, run in order:
     print(f"{name}: {ms:.3f} ms at {cols} columns tier {tier} ({cols / ms / 1e3:.1f} M columns/s)", flush=True)
     D.restore_fields()
     run()
+# and the whole device part of advance() as one call, from the state after init_timestep
+D2, _ = bench.build_state(cols, 0, tier, 0x5EEDE1A0)
+D2.set_snow_age_tables(synth.snow_age_tables())
+st.kokkos_init_timestep(D2)
+D2.snapshot_fields(ALL if cols <= 2_000_000 else bench.SOIL_RESTORE)
+D2.profile_wrapper(st.WRAPPER_NAMES.index("advance_physics"), 1800.0, 5)  # (the canopy scheduling hints settle)
+ms = D2.profile_wrapper(st.WRAPPER_NAMES.index("advance_physics"), 1800.0, steps)
+print(f"advance_physics (the seven fused + soil_temperature + snow_hydrology + surface_fluxes, one call): {ms:.3f} ms at {cols} columns tier {tier} ({cols / ms / 1e3:.1f} M gridcell-steps/s)", flush=True)
+D2.close()
 D.close()

@@ -18,6 +18,12 @@ if sys.argv[1] == "run":
     fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
     D, _ = bench.build_state(cols, 0, tier, 0x5EEDE1A0)
     adv = st.timestep7_fused if fused else st.timestep7
+    if len(sys.argv) > 4 and sys.argv[4] == "advance":
+        from elmkernels_amd import synth
+
+        D.set_snow_age_tables(synth.snow_age_tables())
+        D.snapshot_fields([k for k in D.fields if k != "err_flags"])
+        adv = st.advance_physics
     for _ in range(10):
         D.restore_fields()
         D.sync()

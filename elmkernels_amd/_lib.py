@@ -50,6 +50,8 @@ SIGNATURES = {
     "elmk_timestep7": (C.c_int, [_P, C.c_double]),
     "elmk_timestep7_fused": (C.c_int, [_P, C.c_double]),
     "elmk_advance_physics": (C.c_int, [_P, C.c_double]),
+    "elmk_initialize_state": (C.c_int, [_P]),
+    "elmk_set_init_params": (C.c_int, [_P, C.c_double, _P, _P]),
     "elmk_profile_timestep7_fused": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_soil_temperature": (C.c_int, [_P, C.c_double]),
     "elmk_snow_hydrology": (C.c_int, [_P, C.c_double]),

@@ -74,6 +74,7 @@ struct elmk_ctx {
   // elmk_set_graph: the seven wrappers of elmk_timestep7 captured once as a HIP graph (kernel nodes + the side-stream
   // fork / join of albedo_snicar) and replayed; key = (dt, stream)
   bool use_graph = false;
+  bool have_init_params = false;
   GraphSlot graph[3];  // [0] elmk_timestep7, [1] elmk_timestep7_fused, [2] elmk_advance_physics
   std::string err;
 };
@@ -548,6 +549,18 @@ int elmk_set_pft(elmk_ctx* ctx, const double* psn, const double* alb, const doub
   return ELMK_OK;
 }
 
+int elmk_set_init_params(elmk_ctx* ctx, double organic_max, const double* roota_par, const double* rootb_par)
+{
+  if (!ctx || !roota_par || !rootb_par) return invalid(ctx, "elmk_set_init_params: null table");
+  if (!(organic_max > 0.0)) return invalid(ctx, "elmk_set_init_params: organic_max must be positive");
+  ctx->h.organic_max = organic_max;
+  memcpy(ctx->h.roota_par, roota_par, sizeof ctx->h.roota_par);
+  memcpy(ctx->h.rootb_par, rootb_par, sizeof ctx->h.rootb_par);
+  ctx->dirty = true;
+  ctx->have_init_params = true;
+  return ELMK_OK;
+}
+
 int elmk_set_soilcolor(elmk_ctx* ctx, const double* albsat, const double* albdry)
 {
   if (!ctx || !albsat || !albdry) return invalid(ctx, "elmk_set_soilcolor: null table");
@@ -736,6 +749,15 @@ int elmk_phenology(elmk_ctx* ctx, double wt1, double wt2)
 {
   PHYSICS_PROLOGUE();
   launch_phenology(ctx->d, ctx->ncols, wt1, wt2, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return ELMK_OK;
+}
+
+int elmk_initialize_state(elmk_ctx* ctx)
+{
+  PHYSICS_PROLOGUE();
+  if (!ctx->have_init_params) return invalid(ctx, "elmk_initialize_state: elmk_set_init_params has not been called");
+  launch_initialize_state(ctx->d, ctx->ncols, ctx->stream);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }

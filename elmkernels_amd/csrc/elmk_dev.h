@@ -203,6 +203,9 @@ struct DevState {
 #include "elmk_fields.def"
 #undef ELMK_FIELD
   gptr<uint32_t> err_flags;
+  // cold-start initialisation (k_init_state.hip): organic_max of the parameter file, PFTData::roota_par / rootb_par
+  double organic_max;
+  double roota_par[ELMK_MXPFT], rootb_par[ELMK_MXPFT];
 };
 
 // std::min / std::max of the reference (<algorithm>): first argument wins ties and NaNs

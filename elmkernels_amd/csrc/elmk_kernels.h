@@ -44,6 +44,8 @@ void launch_snow_hydrology(const DevState* S, int64_t n, double dt, hipStream_t 
 constexpr int ELMK_CONS_NPART = 512;  // stage-1 partials per diagnostic
 void launch_surface_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_init_timestep(const DevState* S, int64_t n, hipStream_t st);
+// the per-column init functions of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428), k_init_state.hip
+void launch_initialize_state(const DevState* S, int64_t n, hipStream_t st);
 // the forcing and phenology functors kokkos_init_timestep runs first (k_forcing.hip)
 void launch_get_forcing(const DevState* S, int64_t n, const double* wt1, const double* wt2, int qbot_is_rh, hipStream_t st);
 void launch_phenology(const DevState* S, int64_t n, double wt1, double wt2, hipStream_t st);

@@ -180,6 +180,13 @@ class ELMState:
             setattr(t, name, a.ctypes.data)
         self._chk(self.lib.elmk_set_snicar(self.ctx, C.byref(t)), "set_snicar")
 
+    def set_init_params(self, organic_max, roota_par, rootb_par):
+        """organic_max of the parameter file (initialize_elm_kokkos.cc:312) and PFTData::roota_par / rootb_par [25]."""
+        a = np.ascontiguousarray(roota_par, dtype=np.float64)
+        b = np.ascontiguousarray(rootb_par, dtype=np.float64)
+        assert a.shape == (25,) and b.shape == (25,)
+        self._chk(self.lib.elmk_set_init_params(self.ctx, float(organic_max), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "set_init_params")
+
     def set_snow_age_tables(self, tables):
         """SnwRdsTable: tables [3, 11, 31, 8] = snowage_tau, snowage_kappa, snowage_drdt0."""
         t = np.ascontiguousarray(tables, dtype=np.float64)
@@ -342,6 +349,12 @@ def forcing_time_weights(days_since_record, forc_dt):
     e = days_since_record / forc_dt
     assert 0.0 <= e <= 1.0
     return 1.0 - e, e
+
+
+def initialize_kokkos_elm(S):
+    """The per-column init functions of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428) - cold-start state from
+    topography, snow depth, soil texture and PFT; the file reads of that function stay with the caller."""
+    S._chk(S.lib.elmk_initialize_state(S.ctx), "initialize_state")
 
 
 def kokkos_init_timestep(S):

@@ -240,7 +240,41 @@ def make_state(field_table, n, tier="A", seed=0x5EEDE1A0, perturb=True):
         cols.update(forcing_streams(cols, seed))
     if "mss_bcphi" in cols:
         cols.update(snow_aerosols(cols, seed))
+    if "pct_sand" in cols:
+        cols.update(init_inputs(cols, seed))
     return cols, scal, soil
+
+
+ORGANIC_MAX = 130.0  # kg/m3, the value of the E3SM parameter file (read at initialize_elm_kokkos.cc:320)
+
+
+def init_inputs(cols, seed):
+    """Inputs of the cold-start initialisation (initialize_elm_kokkos.cc:373-428) no fixture carries: surface-data slope and
+    elevation standard deviation, soil texture and organic matter by level (surfdata's PCT_SAND / PCT_CLAY / ORGANIC)."""
+    n = cols["snl"].shape[0]
+    rng = np.random.default_rng(seed + 8191)
+    out = {}
+    out["topo_slope"] = np.where(rng.random(n) < 0.2, 0.2 * rng.random(n), 12.0 * rng.random(n) ** 2)  # both sides of the 0.2 floor
+    out["topo_std"] = np.where(rng.random(n) < 0.2, 10.0 * rng.random(n), 400.0 * rng.random(n))       # both sides of the 10 m floor
+    sand = 5.0 + 85.0 * rng.random((n, 15))
+    clay = (95.0 - sand) * rng.random((n, 15)) + 1.0
+    out["pct_sand"], out["pct_clay"] = sand, clay
+    org = ORGANIC_MAX * rng.random((n, 15)) ** 2                # mostly mineral soil, some peat (om_frac up to 1)
+    org[rng.random(n) < 0.05] = ORGANIC_MAX                      # pure organic columns: the om_frac == 1 branch
+    org[rng.random((n, 15)) < 0.3] = 0.0
+    out["organic"] = org
+    return out
+
+
+def init_snow_depths(n, seed):
+    """Snow depths that reach every branch of init_snow_layers (init_snow_state_impl.hh:67-151), its bin edges included."""
+    rng = np.random.default_rng(seed + 12289)
+    edges = np.array([0.0, 0.01, 0.03, 0.04, 0.07, 0.12, 0.18, 0.29, 0.41, 0.64, 1.5])
+    k = rng.integers(0, len(edges) - 1, n)
+    d = edges[k] + (edges[k + 1] - edges[k]) * rng.random(n)
+    exact = rng.random(n) < 0.1
+    d[exact] = edges[1:][rng.integers(0, len(edges) - 1, int(exact.sum()))]
+    return d
 
 
 def snow_aerosols(cols, seed):

@@ -30,6 +30,7 @@
  *   get_forcing(S, dt, date)        atm_forcing_kokkos.cc:47-75       elmk_get_forcing
  *   update_phenology: ComputePhenology  phenology_kokkos.cc:59-62     elmk_phenology
  *   kokkos_init_timestep's kernel   init_timestep_kokkos.cc:55-75     elmk_init_timestep
+ *   initialize_kokkos_elm's lambda  initialize_elm_kokkos.cc:373-428  elmk_initialize_state
  *   kokkos_soil_temperature(S,dt)   soil_temperature_kokkos.hh        elmk_soil_temperature
  *   kokkos_snow_hydrology(S,dt,t)   snow_hydrology_kokkos.hh          elmk_snow_hydrology
  *   S.snw_rds_table (SnwRdsTable)   src/data/snicar_data.h:75-84      elmk_set_snow_age_tables
@@ -243,6 +244,17 @@ int elmk_surface_fluxes(elmk_ctx *ctx, double dt);
  * dtbegin_column_h2o (what the conservation check starts from), snow capping flag, frac_veg_nosno, frac_iceold.
  * (The forcing / phenology readers before it in that wrapper are I/O and stay with the caller.) */
 int elmk_init_timestep(elmk_ctx *ctx);
+/* The "init functions" lambda ELM::initialize_kokkos_elm runs once per column after the input files are read
+ * (driver/kokkos/initialize_elm_kokkos.cc:373-428): init_topo_slope / init_melt_factor / init_micro_sigma, init_snow_layers,
+ * init_soil_hydraulics, init_vegrootfr, init_soil_temp, init_snow_state, init_soilh2o_state - the producer of the state the
+ * physics calls consume.  Inputs: the fields topo_slope, topo_std, snow_depth, vtype, zsoi / zisoi / dz of the soil levels
+ * and the surface-data soil texture pct_sand, pct_clay, organic (by soil level; wrapper-local Views in the reference,
+ * :309-311), plus elmk_set_init_params: organic_max of the parameter file (:312) and PFTData::roota_par / rootb_par [25]
+ * (pft_data.h:72-73).  Writes topo_slope, n_melt, micro_sigma, snl, dz / zsoi / zisoi of the snow levels, watsat, bsw, sucsat,
+ * watdry, watopt, watfc, tkmg, tkdry, csol, rootfr, t_soisno, t_grnd, h2osno, int_snow, snow_depth, h2osfc, h2ocan,
+ * frac_h2osfc, fwet, fdry, frac_sno, snw_rds, h2osoi_vol, h2osoi_liq, h2osoi_ice. */
+int elmk_set_init_params(elmk_ctx *ctx, double organic_max, const double *roota_par, const double *rootb_par);
+int elmk_initialize_state(elmk_ctx *ctx);
 /* get_forcing (driver/kokkos/atm_forcing_kokkos.cc:47-75), called by kokkos_init_timestep (init_timestep_kokkos.cc:47):
  * the eight ComputeAtmForcing_* functors of src/physics/atm_physics_impl.hh:27-203 - TBOT, PBOT, QBOT|RH, FLDS, FSDS,
  * PREC, WIND, ZBOT - over the fields atm_tbot .. atm_wind (level 0 = forcing record t_idx, level 1 = t_idx + 1 of

@@ -73,6 +73,14 @@ class ELMInterface {
     ok(elmk_set_graph(ctx_, 1));  // advance() replays one HIP graph per step
   }
 
+  /* the per-column part of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428): cold-start state from the
+   * uploaded topography, snow depth, soil texture (fields pct_sand, pct_clay, organic) and PFT; call after the uploads */
+  void initialize(double organic_max, const double* roota_par, const double* rootb_par)
+  {
+    ok(elmk_set_init_params(ctx_, organic_max, roota_par, rootb_par));
+    ok(elmk_initialize_state(ctx_));
+  }
+
   /* one ELMStateViews member, host layout of the reference ([column][level]) */
   void upload(const char* field, const void* host) { ok(elmk_upload(ctx_, id(field), host, 0, ncols_, ELMK_LAYOUT_COL_MAJOR)); }
   void download(const char* field, void* host) { ok(elmk_download(ctx_, id(field), host, 0, ncols_, ELMK_LAYOUT_COL_MAJOR)); }

@@ -166,7 +166,10 @@ typedef struct {
   X(aer_bcphi, D, 1) X(aer_bcpho, D, 1) X(aer_bcdep, D, 1) X(aer_dst1_1, D, 1) X(aer_dst1_2, D, 1)            \
   X(aer_dst2_1, D, 1) X(aer_dst2_2, D, 1) X(aer_dst3_1, D, 1) X(aer_dst3_2, D, 1) X(aer_dst4_1, D, 1)         \
   X(aer_dst4_2, D, 1) X(qflx_top_soil, D, 1) X(mflx_neg_snow, D, 1) X(qflx_snow2topsoi, D, 1)                 \
-  X(mflx_snowlyr_col, D, 1) X(qflx_rootsoi, D, 15)
+  X(mflx_snowlyr_col, D, 1) X(qflx_rootsoi, D, 15)                                                            \
+  /* initialize_kokkos_elm's per-column init functions: S.topo_slope, S.topo_std (elm_state.h) and the wrapper-local soil  \
+     texture Views pct_sand, pct_clay, organic (initialize_elm_kokkos.cc:309-311) */                                      \
+  X(topo_slope, D, 1) X(topo_std, D, 1) X(pct_sand, D, 15) X(pct_clay, D, 15) X(organic, D, 15)
 
 #define ELMO_CT_D double
 #define ELMO_CT_I int
@@ -187,6 +190,10 @@ typedef struct elmo_state {
   elmo_snicar snicar;
   /* SnwRdsTable (snicar_data.h:75-84): snowage_tau / kappa / drdt0 [idx_T 11][idx_Tgrd 31][idx_rhos 8], row-major */
   double snowage[3][ELMO_SNOWAGE_N];
+  /* cold-start initialisation (initialize_elm_kokkos.cc:312, pft_data.h:72-73): organic_max of the parameter file and the
+   * rooting distribution parameters by PFT */
+  double organic_max;
+  double roota_par[ELMO_MXPFT], rootb_par[ELMO_MXPFT];
   /* per-column fields, [col][lev] */
 #define ELMO_DECL(name, kind, nlev) ELMO_CT_##kind *name;
   ELMO_FIELDS(ELMO_DECL)
@@ -229,6 +236,25 @@ void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha
 /* kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188; ELMInterface::advance :313, between soil_temperature and
  * surface_fluxes); elmo_physics_g.c.  PARITY UNPINNED (see that file's header). */
 void elmo_snow_hydrology(elmo_state *S, double dt);
+/* the "init functions" lambda of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428); elmo_physics_h.c */
+void elmo_initialize_state(elmo_state *S);
+void elmo_set_init_params(elmo_state *S, double organic_max, const double *roota_par, const double *rootb_par);
+double elmo_init_topo_slope(double raw_topo_slope);
+double elmo_init_melt_factor(int ltype, double topo_std);
+double elmo_init_micro_sigma(double topo_slope);
+void elmo_init_snow_layers(double snow_depth, int lakpoi, int *snl_io, double *dz, double *z, double *zi);
+void elmo_soil_hydraulic_params(double pct_sand, double pct_clay, double zsoi, double om_frac, double *watsat, double *bsw,
+                                double *sucsat, double *watdry, double *watopt, double *watfc, double *tkmg, double *tkdry,
+                                double *csol);
+void elmo_init_soil_hydraulics(double organic_max, const double *pct_sand, const double *pct_clay, const double *organic,
+                               const double *zsoi, double *watsat, double *bsw, double *sucsat, double *watdry,
+                               double *watopt, double *watfc, double *tkmg, double *tkdry, double *csol);
+void elmo_init_vegrootfr(int vtype, double roota_par, double rootb_par, const double *zi, double *rootfr);
+void elmo_init_soil_temp(const elmo_land *L, int snl, double *t_soisno, double *t_grnd);
+void elmo_init_snow_state(int urbpoi, int snl, double *h2osno, double *int_snow, double *snow_depth, double *h2osfc,
+                          double *h2ocan, double *frac_h2osfc, double *fwet, double *fdry, double *frac_sno, double *snw_rds);
+void elmo_init_soilh2o_state(const elmo_land *L, int snl, const double *watsat, const double *t_soisno, const double *dz,
+                             double *h2osoi_vol, double *h2osoi_liq, double *h2osoi_ice);
 double *elmo_snowage_ptr(elmo_state *S); /* 3 x ELMO_SNOWAGE_N: tau, kappa, drdt0 */
 void elmo_snow_aging(int do_capsnow, int snl, double frac_sno, double dtime, double qflx_snwcp_ice, double qflx_snow_grnd,
                      double h2osno, const double *dz, const double *h2osoi_liq, const double *h2osoi_ice,

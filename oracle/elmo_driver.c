@@ -546,6 +546,38 @@ void elmo_init_timestep(elmo_state *S)
   }
 }
 
+void elmo_set_init_params(elmo_state *S, double organic_max, const double *roota_par, const double *rootb_par)
+{
+  S->organic_max = organic_max;
+  for (int p = 0; p < ELMO_MXPFT; p++) {
+    S->roota_par[p] = roota_par[p];
+    S->rootb_par[p] = rootb_par[p];
+  }
+}
+
+/* the "init functions" lambda of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428), in its order.  (Its first
+ * line, S.psn_pft(idx) = pft_data.get_pft_psn(S.vtype(idx)), is the PFT-table lookup every wrapper here does by vtype.) */
+void elmo_initialize_state(elmo_state *S)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    S->topo_slope[c] = elmo_init_topo_slope(S->topo_slope[c]);
+    S->n_melt[c] = elmo_init_melt_factor(S->land.ltype, S->topo_std[c]);
+    S->micro_sigma[c] = elmo_init_micro_sigma(S->topo_slope[c]);
+    elmo_init_snow_layers(S->snow_depth[c], S->land.lakpoi, &S->snl[c], LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21));
+    elmo_init_soil_hydraulics(S->organic_max, LV(pct_sand, 15), LV(pct_clay, 15), LV(organic, 15), LV(zsoi, 20), LV(watsat, 15),
+                              LV(bsw, 15), LV(sucsat, 15), LV(watdry, 15), LV(watopt, 15), LV(watfc, 15), LV(tkmg, 15),
+                              LV(tkdry, 15), LV(csol, 20));
+    const int vt = S->vtype[c];
+    elmo_init_vegrootfr(vt, S->roota_par[vt], S->rootb_par[vt], LV(zisoi, 21), LV(rootfr, 15));
+    elmo_init_soil_temp(&S->land, S->snl[c], LV(t_soisno, 20), &S->t_grnd[c]);
+    elmo_init_snow_state(S->land.urbpoi, S->snl[c], &S->h2osno[c], &S->int_snow[c], &S->snow_depth[c], &S->h2osfc[c],
+                         &S->h2ocan[c], &S->frac_h2osfc[c], &S->fwet[c], &S->fdry[c], &S->frac_sno[c], LV(snw_rds, 5));
+    elmo_init_soilh2o_state(&S->land, S->snl[c], LV(watsat, 15), LV(t_soisno, 20), LV(dz, 20), LV(h2osoi_vol, 15),
+                            LV(h2osoi_liq, 20), LV(h2osoi_ice, 20));
+  }
+}
+
 /* conserved_quantity_kokkos.cc:8-81 */
 void elmo_evaluate_conservation(elmo_state *S, double dt, double *diag)
 {

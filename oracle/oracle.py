@@ -73,6 +73,8 @@ class _Lib:
         L.elmo_albedo_snicar_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elmo_soil_temperature.argtypes = [C.c_void_p, C.c_double]
         L.elmo_snow_hydrology.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_initialize_state.argtypes = [C.c_void_p]
+        L.elmo_set_init_params.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
         L.elmo_soil_thermal.argtypes = [C.c_void_p] * 5
         L.elmo_surface_fluxes.argtypes = [C.c_void_p, C.c_double]
@@ -101,6 +103,8 @@ class _Lib:
             if hasattr(R, "elmref_init_timestep"):
                 R.elmref_init_timestep.argtypes = [C.c_void_p]
                 R.elmref_evaluate_conservation.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+            if hasattr(R, "elmref_initialize_state"):
+                R.elmref_initialize_state.argtypes = [C.c_void_p]
             if hasattr(R, "elmref_get_forcing"):
                 R.elmref_get_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                 R.elmref_phenology.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -160,6 +164,7 @@ class OracleState:
             self.snicar[name] = _view(off, (n,), np.float64)
             off += n * 8
         self.scalars = dict(ltype=1, ctype=0, vtype=2, urbpoi=0, lakpoi=0, dewmx=0.1, oldfflag=1, dayl=0.0, max_dayl=0.0)
+        self.init_params = None
 
     def __del__(self):
         try:
@@ -200,6 +205,8 @@ class OracleState:
         for k in self.snicar:
             self.snicar[k][...] = other.snicar[k]
         self.snowage[...] = other.snowage
+        if getattr(other, "init_params", None) is not None:
+            self.set_init_params(*other.init_params)
         self.set_scalars(**other.scalars)
 
     def clone(self):
@@ -269,6 +276,18 @@ class OracleState:
     def snow_hydrology(self, dt):
         """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188); parity unpinned (oracle/elmo_physics_g.c)."""
         self._L.lib.elmo_snow_hydrology(self.ptr, float(dt))
+
+    def set_init_params(self, organic_max, roota_par, rootb_par):
+        """organic_max of the parameter file (initialize_elm_kokkos.cc:312) and PFTData::roota_par / rootb_par [25]."""
+        a = np.ascontiguousarray(roota_par, dtype=np.float64)
+        b = np.ascontiguousarray(rootb_par, dtype=np.float64)
+        assert a.shape == (25,) and b.shape == (25,)
+        self.init_params = (float(organic_max), a.copy(), b.copy())
+        self._L.lib.elmo_set_init_params(self.ptr, float(organic_max), a.ctypes.data, b.ctypes.data)
+
+    def initialize_state(self, lib=None):
+        """The per-column init functions of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428)."""
+        (self._L.lib.elmo_initialize_state if lib is None else lib.elmref_initialize_state)(self.ptr)
 
     def init_timestep(self, lib=None):
         (self._L.lib.elmo_init_timestep if lib is None else lib.elmref_init_timestep)(self.ptr)

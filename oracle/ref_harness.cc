@@ -9,6 +9,7 @@
 //   canopy_hydrology.h  surface_radiation.h  canopy_temperature.h (+qsat.h, surface_resistance.h)
 //   bareground_fluxes.h (+friction_velocity.h)  snow_snicar.h  soil_moist_stress.h  atm_physics.h
 //   soil_thermal_properties.h  pentadiagonal_solver.h  phase_change.h  surface_fluxes.h  conserved_quantity_evaluators.h
+//   init_topography.h  init_snow_state.h  soil_texture_hydraulic_model.h  init_soil_state.h
 // Not covered (unbuildable here: pft_data.h -> read_input.hh -> read_netcdf.hh -> netcdf.h):
 //   canopy_fluxes.h  photosynthesis.h  surface_albedo.h
 // The loops below follow the argument wiring of driver/kokkos/*_kokkos.cc (cited per function).
@@ -36,6 +37,11 @@
 #include "init_timestep.h"
 #include "atm_physics.h"
 #include "phenology_physics.h"
+// cold-start initialisation (initialize_elm_kokkos.cc:373-428)
+#include "init_snow_state.h"
+#include "init_soil_state.h"
+#include "init_topography.h"
+#include "soil_texture_hydraulic_model.h"
 
 #include "elm_oracle.h"
 
@@ -523,4 +529,27 @@ void elmref_phenology(elmo_state* S, double wt1, double wt2)
                                                     esai, htop, hbot, tlai, tsai, fvna);
   for (int c = 0; c < n; c++) f(c);
 }
+// the "init functions" lambda of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428), with the reference's own
+// functions in its order
+void elmref_initialize_state(elmo_state* S)
+{
+  const ELM::LandType L = land_of(S);
+  for (int64_t c = 0; c < S->ncols; c++) {
+    S->topo_slope[c] = ELM::init_topo_slope(S->topo_slope[c]);
+    S->n_melt[c] = ELM::init_melt_factor(L.ltype, S->topo_std[c]);
+    S->micro_sigma[c] = ELM::init_micro_sigma(S->topo_slope[c]);
+    ELM::init_snow_layers(S->snow_depth[c], L.lakpoi, S->snl[c], V(dz, 20), V(zsoi, 20), V(zisoi, 21));
+    ELM::init_soil_hydraulics(S->organic_max, V(pct_sand, 15), V(pct_clay, 15), V(organic, 15), V(zsoi, 20), V(watsat, 15),
+                              V(bsw, 15), V(sucsat, 15), V(watdry, 15), V(watopt, 15), V(watfc, 15), V(tkmg, 15), V(tkdry, 15),
+                              V(csol, 20));
+    const int vt = S->vtype[c];
+    ELM::init_vegrootfr(vt, S->roota_par[vt], S->rootb_par[vt], V(zisoi, 21), V(rootfr, 15));
+    ELM::init_soil_temp(L, S->snl[c], V(t_soisno, 20), S->t_grnd[c]);
+    ELM::init_snow_state(L.urbpoi, S->snl[c], S->h2osno[c], S->int_snow[c], S->snow_depth[c], S->h2osfc[c], S->h2ocan[c],
+                         S->frac_h2osfc[c], S->fwet[c], S->fdry[c], S->frac_sno[c], V(snw_rds, 5));
+    ELM::init_soilh2o_state(L, S->snl[c], V(watsat, 15), V(t_soisno, 20), V(dz, 20), V(h2osoi_vol, 15), V(h2osoi_liq, 20),
+                            V(h2osoi_ice, 20));
+  }
+}
+
 } // extern "C"

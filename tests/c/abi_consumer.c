@@ -18,6 +18,7 @@ int drive_one_step(int64_t ncols, const double *t_soisno_cols /* [ncols][20], th
   rc = elmk_set_land(ctx, 1, 1, 12, 0, 0);
   if (rc == ELMK_OK) rc = elmk_set_scalars(ctx, 0.1, 1, 43200.0, 86400.0);
   if (rc == ELMK_OK) rc = elmk_upload(ctx, ELMK_FIELD_t_soisno, t_soisno_cols, 0, ncols, ELMK_LAYOUT_COL_MAJOR);
+  if (rc == ELMK_OK) rc = elmk_initialize_state(ctx);
   if (rc == ELMK_OK) rc = elmk_timestep7(ctx, dt);
   if (rc == ELMK_OK) rc = elmk_timestep7_fused(ctx, dt);
   if (rc == ELMK_OK) rc = elmk_soil_temperature(ctx, dt);

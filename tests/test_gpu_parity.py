@@ -265,6 +265,45 @@ def test_cpp_interface_mirror(tmp_path):
     np.testing.assert_allclose(got[:, 2], diag.sum(axis=0), rtol=1e-9, atol=1e-6)  # (sums: association order)
 
 
+
+def test_initialize_state_then_advance():
+    """ELM::initialize_kokkos_elm's per-column init functions (initialize_elm_kokkos.cc:373-428) on the device - every land
+    unit, every branch of the initial snow mesh, mineral to pure organic soil - bit-identical to the oracle, which is pinned
+    bit for bit against the reference's own headers (tests/test_oracle_vs_ref.py::test_initialize_state_bitwise); then the
+    cold-start state goes straight into two advance() steps on the device, still bit-identical."""
+    pft, _ = synth.load_params()
+    lands = [dict(ltype=1, ctype=0, vtype=2, urbpoi=0, lakpoi=0), dict(ltype=4, ctype=0, vtype=0, urbpoi=0, lakpoi=0),
+             dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0), dict(ltype=5, ctype=0, vtype=0, urbpoi=0, lakpoi=1),
+             dict(ltype=7, ctype=71, vtype=0, urbpoi=1, lakpoi=0), dict(ltype=7, ctype=75, vtype=0, urbpoi=1, lakpoi=0)]
+    for k, land in enumerate(lands):
+        n = 6016
+        ft = st.field_table()
+        cols, scal, soil = synth.make_state(ft, n, tier="B", seed=400 + k)
+        cols["snow_depth"] = synth.init_snow_depths(n, 400 + k)
+        vt = cols["vtype"].copy()
+        vt[::9] = 0
+        cols["vtype"] = vt
+        S = H.oracle_state(cols, scal, soil, land)
+        D = H.device_state(cols, scal, soil, land)
+        S.set_init_params(synth.ORGANIC_MAX, pft["roota_par"], pft["rootb_par"])
+        D.set_init_params(synth.ORGANIC_MAX, pft["roota_par"], pft["rootb_par"])
+        st.initialize_kokkos_elm(D)
+        S.initialize_state()
+        _check(D, S, f"initialize_state, land {land}", bitwise=True)
+        assert set(np.unique(S["snl"]).tolist()) == ({0} if land["lakpoi"] else {0, 1, 2, 3, 4, 5})
+        if k == 0:  # soil columns: the freshly initialised state through the whole advance() order, twice
+            for step in range(2):
+                st.kokkos_init_timestep(D)
+                S.init_timestep()
+                st.advance_physics(D, DT)
+                S.timestep7(DT)
+                S.soil_temperature(DT)
+                S.snow_hydrology(DT)
+                S.surface_fluxes(DT)
+                _check(D, S, f"advance() step {step} from the cold-start state", bitwise=True)
+        D.close()
+
+
 def test_other_land_units():
     """Non-soil land units take the short branches of every routine (wetland, land ice, lake, urban)."""
     for land in (dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0), dict(ltype=3, ctype=0, vtype=0, urbpoi=0, lakpoi=0),

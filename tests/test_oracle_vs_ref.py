@@ -296,3 +296,36 @@ def test_get_forcing_and_phenology_bitwise(states):
     B.phenology(0.3, 0.7, lib=R)
     assert not _same(A, B)
     assert (A["frac_veg_nosno_alb"] == 0).any() and (A["frac_veg_nosno_alb"] == 1).any() and (A["elai"] == 0).any()
+
+
+def test_initialize_state_bitwise():
+    """The per-column init functions of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428: topography, the initial
+    snow mesh, soil hydraulic / thermal parameters, root fractions, initial temperature and water) - the producer of the
+    state the hot path consumes.  All four reference headers compile here: the restatement (oracle/elmo_physics_h.c) equals
+    the reference bit for bit, on every land unit, every snow-depth bin (edges included), mineral to pure organic soil."""
+    R = O.Reference().R
+    if not hasattr(R, "elmref_initialize_state"):
+        pytest.skip("reference library predates elmref_initialize_state")
+    pft, _ = synth.load_params()
+    ft = H.field_table_from_oracle()
+    lands = [dict(ltype=1, ctype=0, urbpoi=0, lakpoi=0), dict(ltype=2, ctype=0, urbpoi=0, lakpoi=0),
+             dict(ltype=3, ctype=0, urbpoi=0, lakpoi=0), dict(ltype=4, ctype=0, urbpoi=0, lakpoi=0),
+             dict(ltype=6, ctype=0, urbpoi=0, lakpoi=0), dict(ltype=5, ctype=0, urbpoi=0, lakpoi=1),
+             dict(ltype=7, ctype=71, urbpoi=1, lakpoi=0), dict(ltype=7, ctype=73, urbpoi=1, lakpoi=0),
+             dict(ltype=7, ctype=74, urbpoi=1, lakpoi=0), dict(ltype=7, ctype=75, urbpoi=1, lakpoi=0)]
+    seen_snl = set()
+    for k, land in enumerate(lands):
+        cols, scal, soil = synth.make_state(ft, N, tier="B", seed=300 + k)
+        cols["snow_depth"] = synth.init_snow_depths(N, 300 + k)
+        vt = cols["vtype"].copy()
+        vt[::9] = 0  # PFT::noveg: the zero-root branch
+        cols["vtype"] = vt
+        A = H.oracle_state(cols, scal, soil, dict(land, vtype=2))
+        A.set_init_params(synth.ORGANIC_MAX, pft["roota_par"], pft["rootb_par"])
+        B = A.clone()
+        A.initialize_state()
+        B.initialize_state(lib=R)
+        assert _same(A, B) == {}, land
+        seen_snl |= set(np.unique(A["snl"]).tolist())
+        assert np.isfinite(A["watsat"]).all() and (A["watsat"] > 0).all() and (A["watsat"] < 1).all()
+    assert seen_snl == {0, 1, 2, 3, 4, 5}

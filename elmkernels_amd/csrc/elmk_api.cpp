@@ -1015,7 +1015,7 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
   const void* src = nullptr;
   size_t esz = 0;
   int64_t limit = 0;
-  if (kind == ELMK_SCRATCH_CF_TRIPS) {
+  if (kind == ELMK_SCRATCH_CF_TRIPS || kind == ELMK_SCRATCH_CF_HINTS) {
     src = ELMK_GENERIC(ctx->h.cf_niter);
     esz = 4;
     limit = ctx->ncols;
@@ -1031,6 +1031,8 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (kind == ELMK_SCRATCH_CF_TRIPS)  // the high half of each word is the scheduler's hint
     for (int64_t i = 0; i < count; i++) ((int32_t*)host)[i] &= 0xFFFF;
+  if (kind == ELMK_SCRATCH_CF_HINTS)
+    for (int64_t i = 0; i < count; i++) ((int32_t*)host)[i] >>= 16;
   return ELMK_OK;
 }
 

@@ -959,7 +959,11 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       if ((uint32_t)nidle > have && !exhausted) {
         const uint32_t need = (uint32_t)nidle - have;
         // no hoarding near the end of the queue: with fewer than CF_BLOCK_EXTRA positions per wave left, claim exactly
-        const uint32_t extra = (nq - last_base > (uint32_t)CF_BLOCK_EXTRA * nwaves_total) ? (uint32_t)CF_BLOCK_EXTRA : 0u;
+        // ... and none at the head either: the first claim of every wave takes exactly its 64 positions, so that the whole
+        // head of the queue - the longest classes - starts at time zero (positions held back there would start at the
+        // first refill, ~22 trips in: a 41-trip column among them ended at trip 63 and set the kernel's tail, +0.5 ms on
+        // the branch-mix tier)
+        const uint32_t extra = (blk_end != 0u && nq - last_base > (uint32_t)CF_BLOCK_EXTRA * nwaves_total) ? (uint32_t)CF_BLOCK_EXTRA : 0u;
         const uint32_t want = need + extra;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(ELMK_GENERIC(&ELMK_LIST_HEAD(S, LIST_CF_QUEUE)), want);

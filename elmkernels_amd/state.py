@@ -226,6 +226,12 @@ class ELMState:
         self._chk(self.lib.elmk_read_scratch(self.ctx, 0, out.ctypes.data_as(C.c_void_p), 0, self.ncols), "read_scratch")
         return out
 
+    def canopy_schedule_hints(self):
+        """The scheduler's hint per column: slowly decaying maximum of the trip count (development diagnostics)."""
+        out = np.zeros(self.ncols, dtype=np.int32)
+        self._chk(self.lib.elmk_read_scratch(self.ctx, 2, out.ctypes.data_as(C.c_void_p), 0, self.ncols), "read_scratch")
+        return out
+
     def read_work(self, offset, count):
         out = np.zeros(int(count), dtype=np.float64)
         self._chk(self.lib.elmk_read_scratch(self.ctx, 1, out.ctypes.data_as(C.c_void_p), int(offset), int(count)), "read_scratch")

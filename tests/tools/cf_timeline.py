@@ -16,6 +16,7 @@ for _ in range(int(os.environ.get('CF_WARM', '2'))):
     D.restore_fields()
     st.timestep7(D, 1800.0)
 prev = D.canopy_trip_counts()
+hint = D.canopy_schedule_hints()
 D.restore_fields()
 st.timestep7(D, 1800.0)
 D.sync()
@@ -24,6 +25,9 @@ d = trips - prev
 print("trip count change between the last two steps: changed", int((d != 0).sum()), "|d|>5:", int((abs(d) > 5).sum()),
       "hint<=5 but now >=12:", int(((prev <= 5) & (prev > 0) & (trips >= 12)).sum()), "max", int(abs(d).max()))
 veg = trips > 0
+longc = trips >= 30
+print("columns with >= 30 trips now:", int(longc.sum()), "of which the scheduler's hint was < 22:", int((longc & (hint < 22)).sum()),
+      "< 16:", int((longc & (hint < 16)).sum()), "< 12:", int((longc & (hint < 12)).sum()))
 day = (D.download("nrad") > 0) & ((D.download("parsun_z").reshape(cols, -1)[:, 0] > 0) | (D.download("parsha_z").reshape(cols, -1)[:, 0] > 0))
 for lo, hi in ((1, 5), (6, 8), (9, 11), (12, 15), (16, 21), (22, 41)):
     for nm, mk in (("day", day), ("night", ~day)):

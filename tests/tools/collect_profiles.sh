@@ -12,3 +12,7 @@ for f in hbm_traffic_pmc_tierA.json hbm_traffic_pmc_tierB.json hbm_traffic_pmc_f
   cp $O/$f profiles/${P}_$f
 done
 ls profiles | grep "^${P}_"
+# the SQ counter summary and step timelines of tests/tools/pmc_round.sh, if that was run too (gpurun_out/pmc_r2/)
+for f in pmc_counters tl_per_wrapper_tierA tl_fused_tierA tl_fused_tierB tl_advance_tierB; do
+  [ -f gpurun_out/pmc_r2/$f.txt ] && cp gpurun_out/pmc_r2/$f.txt profiles/${P}_$f.txt
+done

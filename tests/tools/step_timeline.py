@@ -24,7 +24,7 @@ if sys.argv[1] == "run":
         D.set_snow_age_tables(synth.snow_age_tables())
         D.snapshot_fields([k for k in D.fields if k != "err_flags"])
         adv = st.advance_physics
-    for _ in range(10):
+    for _ in range(25):  # (as many steps as bench.py runs: the scheduling hints are a decaying maximum over past steps)
         D.restore_fields()
         D.sync()
         adv(D, 1800.0)

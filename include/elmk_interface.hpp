@@ -13,6 +13,8 @@
  *
  * Nothing here touches HIP or torch: plain C++17 over the extern "C" entry points. */
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -22,6 +24,84 @@
 #include "elmk.h"
 
 namespace elmk {
+
+/* The host scalars kokkos_init_timestep computes before its kernels (init_timestep_kokkos.cc:26-34): the cosine of the solar
+ * zenith angle averaged over the step, the day length and its yearly maximum.  Plain <cmath> on the host, as in the
+ * reference (src/physics/incident_shortwave.cc:14-121, day_length.cc:15-39), so the values are the reference's bits on the
+ * same libm; checked against the reference's own sources compiled into oracle/_ref (tests/test_host_side.py). */
+namespace solar {
+constexpr double PI = 3.14159265358979323846;  // ELMconst::ELM_PI
+constexpr double TWO_PI = PI * 2.0;
+constexpr double PI_OVER_TWO = PI / 2.0;
+
+/* incident_shortwave.cc:17 (lnd_import szenith() / shr_orb_cosz()) */
+inline double declination_angle_sin(int doy) { return 23.45 * PI / 180.0 * std::sin(TWO_PI * (284.0 + doy) / 365.0); }
+/* :29-31 */
+inline double ensure_tan_defined(double var) { return (var == PI_OVER_TWO) ? var - 1.0e-05 : (var == -PI_OVER_TWO) ? var + 1.0e-05 : var; }
+/* :37-42: start of the step as an hour angle on [-pi, pi) */
+inline double dt_start_rad(double jday, double lonrad)
+{
+  const double t_start = (jday - std::floor(jday)) * TWO_PI + lonrad - PI;
+  return (t_start >= PI) ? t_start - TWO_PI : (t_start < -PI) ? t_start + TWO_PI : t_start;
+}
+/* :52-56: half-day length [0, pi] */
+inline double coshalfday(double latrad, double declin)
+{
+  const double cos_h = -std::tan(ensure_tan_defined(latrad)) * std::tan(ensure_tan_defined(declin));
+  return (cos_h <= -1.0) ? PI : (cos_h >= 1.0) ? 0.0 : std::acos(cos_h);
+}
+/* :61-94 */
+inline void avg_hourangle(double t_start, double t_end, double dtrad, double cos_h, double ha[4])
+{
+  auto clamp = [](double v, double lo, double hi) { return std::min(std::max(v, lo), hi); };
+  if (t_end >= PI && t_start <= PI && PI - cos_h <= dtrad) {
+    ha[0] = clamp(t_start, -cos_h, cos_h);
+    ha[1] = cos_h;
+    ha[2] = TWO_PI - cos_h;
+    ha[3] = clamp(t_end, TWO_PI - cos_h, TWO_PI + cos_h);
+  } else if (t_end >= -PI && t_start <= -PI && PI - cos_h <= dtrad) {
+    ha[0] = clamp(t_start, -TWO_PI - cos_h, -TWO_PI + cos_h);
+    ha[1] = -TWO_PI + cos_h;
+    ha[2] = -cos_h;
+    ha[3] = clamp(t_end, -cos_h, cos_h);
+  } else {
+    ha[0] = clamp((t_start > PI) ? t_start - TWO_PI : (t_start < -PI) ? t_start + TWO_PI : t_start, -cos_h, cos_h);
+    ha[1] = clamp((t_end > PI) ? t_end - TWO_PI : (t_end < -PI) ? t_end + TWO_PI : t_end, -cos_h, cos_h);
+    ha[2] = 0.0;
+    ha[3] = 0.0;
+  }
+}
+/* :98-121: Zhou et al. (2015) average of cos(zenith) over [t, t + dt] */
+inline double average_cosz(double latrad, double lonrad, double dt, double jday)
+{
+  const double dtrad = dt * TWO_PI / 86400.0;
+  const double t_start = dt_start_rad(jday, lonrad);
+  const double t_end = t_start + dtrad;
+  const double declin = declination_angle_sin(static_cast<int>(jday));
+  const double cos_h = coshalfday(latrad, declin);
+  const double aa = std::sin(latrad) * std::sin(declin);
+  const double bb = std::cos(latrad) * std::cos(declin);
+  double ha[4];
+  avg_hourangle(t_start, t_end, dtrad, cos_h, ha);
+  return (ha[1] > ha[0] || ha[3] > ha[2])
+             ? (aa * (ha[1] - ha[0]) + bb * (std::sin(ha[1]) - std::sin(ha[0]))) / dtrad +
+                   (aa * (ha[3] - ha[2]) + bb * (std::sin(ha[3]) - std::sin(ha[2]))) / dtrad
+             : 0.0;
+}
+/* day_length.cc:15-34 (seconds); lat and decl in radians */
+inline double daylength(double lat, double decl)
+{
+  const double secs_per_radian = 13750.9871;
+  const double lat_epsilon = 10.0 * 2.220446049250313e-16;
+  const double offset_pole = PI / 2.0 - lat_epsilon;
+  const double my_lat = std::min(offset_pole, std::max(1.0 * offset_pole, lat));  // (the reference's own expression, :28)
+  double temp = -(std::sin(my_lat) * std::sin(decl)) / (std::cos(my_lat) * std::cos(decl));
+  temp = std::min(1.0, std::max(-1.0, temp));
+  return 2.0 * secs_per_radian * std::acos(temp);
+}
+/* :39 */
+inline double max_daylength(double lat) { return (lat < 0.0) ? daylength(lat, -0.409571) : daylength(lat, 0.409571); }
+}  // namespace solar
 
 /* ELM::PrimaryVars<ViewI1, ViewD1, ViewD2> (src/data/elm_state.h:17-48) on the host: [column][level], level fastest,
  * as the reference's Views are (src/utils/array.hh:176-179) */
@@ -102,6 +182,15 @@ class ELMInterface {
       throw std::runtime_error("ELM physics error flags " + std::to_string(flags) + ", first at column " + std::to_string(col));
     last_flags_ = flags;
     return false;
+  }
+
+  /* the host scalars of kokkos_init_timestep (init_timestep_kokkos.cc:26-34) for one location: coszen for every column
+   * (Utils::assign(S.coszen, cosz)), S.dayl and S.max_dayl.  decday = Utils::decimal_doy(date) + 1.0, doy = date.doy. */
+  void set_solar_geometry(double lat_r, double lon_r, double dt_seconds, double decday, int doy, double dewmx, int oldfflag)
+  {
+    ok(elmk_fill(ctx_, id("coszen"), solar::average_cosz(lat_r, lon_r, dt_seconds, decday)));
+    ok(elmk_set_scalars(ctx_, dewmx, oldfflag, solar::daylength(lat_r, solar::declination_angle_sin(doy + 1)),
+                        solar::max_daylength(lat_r)));
   }
 
   /* ELMInterface::copyPrimaryVars / getPrimaryVars (elm_kokkos_interface.cc:324-356) */

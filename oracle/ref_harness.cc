@@ -42,6 +42,11 @@
 #include "init_soil_state.h"
 #include "init_topography.h"
 #include "soil_texture_hydraulic_model.h"
+// the host scalars of kokkos_init_timestep: the reference's two small source files, compiled into this library as they lie
+#include "day_length.h"
+#include "incident_shortwave.h"
+#include "day_length.cc"
+#include "incident_shortwave.cc"
 
 #include "elm_oracle.h"
 
@@ -549,6 +554,17 @@ void elmref_initialize_state(elmo_state* S)
                          S->frac_h2osfc[c], S->fwet[c], S->fdry[c], S->frac_sno[c], V(snw_rds, 5));
     ELM::init_soilh2o_state(L, S->snl[c], V(watsat, 15), V(t_soisno, 20), V(dz, 20), V(h2osoi_vol, 15), V(h2osoi_liq, 20),
                             V(h2osoi_ice, 20));
+  }
+}
+
+// incident_shortwave.cc / day_length.cc on arrays of arguments (init_timestep_kokkos.cc:26-34)
+void elmref_solar(int64_t n, const double* lat, const double* lon, const double* dt, const double* jday, double* cosz,
+                  double* dayl, double* max_dayl)
+{
+  for (int64_t i = 0; i < n; i++) {
+    cosz[i] = ELM::incident_shortwave::average_cosz(lat[i], lon[i], dt[i], jday[i]);
+    dayl[i] = ELM::daylength(lat[i], ELM::incident_shortwave::declination_angle_sin(static_cast<int>(jday[i])));
+    max_dayl[i] = ELM::max_daylength(lat[i]);
   }
 }
 

@@ -148,3 +148,42 @@ def test_cpp_interface_mirror_compiles_and_links():
     hdr = open(os.path.join(ROOT, "include", "elmk_interface.hpp")).read()
     for member in ("void setup(", "bool advance(", "void copyPrimaryVars(", "getPrimaryVars()"):
         assert member in hdr, member
+
+
+def test_solar_geometry_matches_the_reference_sources():
+    """The host scalars kokkos_init_timestep computes before its kernels - step-averaged cos(zenith), day length, maximum day
+    length (init_timestep_kokkos.cc:26-34) - as include/elmk_interface.hpp restates them, against the reference's own
+    incident_shortwave.cc and day_length.cc compiled into oracle/_ref: bit for bit over latitudes pole to pole (the poles
+    themselves included), every longitude, every day of the year, steps from a minute to a day."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+
+    from oracle import oracle as O
+
+    if not O.have_ref() or not hasattr(O.Reference().R, "elmref_solar"):
+        pytest.skip("oracle/_ref/libelmref.so not built here (or predates elmref_solar)")
+    R = O.Reference().R
+    rng = np.random.default_rng(17)
+    n = 200_000
+    lat = (rng.random(n) - 0.5) * np.pi
+    lat[:4] = [np.pi / 2, -np.pi / 2, 0.0, 1.2]
+    lon = (rng.random(n) - 0.5) * 4 * np.pi
+    dt = rng.choice([60.0, 1800.0, 3600.0, 10800.0, 86400.0], n)
+    jday = 1.0 + 365.0 * rng.random(n)
+    jday[::7] = np.floor(jday[::7])  # midnight: the fractional day is exactly zero
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "solar.so")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "c", "solar_shim.cc"), "-o", so])
+        L = C.CDLL(so)
+        out = {}
+        for name, fn in (("mine", L.elmk_test_solar), ("ref", R.elmref_solar)):
+            fn.argtypes = [C.c_int64] + [C.c_void_p] * 7
+            fn.restype = None
+            o = [np.zeros(n) for _ in range(3)]
+            fn(n, lat.ctypes.data, lon.ctypes.data, dt.ctypes.data, jday.ctypes.data, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data)
+            out[name] = o
+    for a, b, what in zip(out["mine"], out["ref"], ("average_cosz", "daylength", "max_daylength")):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), what
+    assert (out["ref"][0] > 0).mean() > 0.3 and (out["ref"][0] == 0).mean() > 0.2  # day and night both sampled

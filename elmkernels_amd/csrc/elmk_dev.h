@@ -166,7 +166,9 @@ __device__ __forceinline__ void block_classify_append(gptr<int32_t> lists, int64
     s_base[threadIdx.x] = n ? atomicAdd(ELMK_GENERIC(&counters[(first_list + threadIdx.x) * CPAD]), n) : 0u;
   }
   __syncthreads();
-  if (cls >= 0) lists[(int64_t)(first_list + cls) * ld + s_base[cls] + my_off] = c;
+  // (a list holds at most every column once; the bound only matters if a caller's earlier step was cut short by a HIP error
+  //  between filling and draining a list, when its counter is not back at zero)
+  if (cls >= 0 && (int64_t)s_base[cls] + my_off < ld) lists[(int64_t)(first_list + cls) * ld + s_base[cls] + my_off] = c;
 }
 
 // Everything a kernel needs, resident in device memory (kernels get one pointer; all loads from this

@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict
 template <int NL>
 __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restrict__ S)
 {
-  const uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
+  uint32_t count = ELMK_LIST_COUNT(S, LIST_ALB_0 + NL);
+  if ((int64_t)count > S->ld) count = (uint32_t)S->ld;  // (a list never holds more than every column: block_classify_append)
   // nothing in the queue for this workgroup (the whole launch, when no column has NL layers): leave before the table copy
   if ((uint64_t)blockIdx.x * (blockDim.x >> 6) * 6u >= count) return;
   elmk_math_lds_init<false>();

@@ -1535,7 +1535,8 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
   for (int t = 0; t < FZ_PREP_TILES; t++) {
     if (apack[t] != 0xffffffffu) {
       const int k = (int)(apack[t] >> 16);
-      S->lists[(int64_t)(LIST_ALB_1 + k) * ld + a_base[k] + (apack[t] & 0xffffu)] = (int32_t)((tile0 + t) * 256 + threadIdx.x);
+      const int64_t at = (int64_t)a_base[k] + (apack[t] & 0xffffu);
+      if (at < ld) S->lists[(int64_t)(LIST_ALB_1 + k) * ld + at] = (int32_t)((tile0 + t) * 256 + threadIdx.x);  // (bound: see block_classify_append)
     }
   }
 }

@@ -583,10 +583,11 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict__ S)
 {
-  elmk_math_lds_init<false>();
+  const Land L = S->land;
+  // (stage 1 evaluates exp on deep-lake columns only - the ice fraction of soil_albedo: no table copy for the other land units)
+  if (L.ltype == istdlak) elmk_math_lds_init<false>();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ld = S->ld;
-  const Land L = S->land;
   if (L.urbpoi) return;  // every routine of this wrapper is a no-op on urban points
   const bool inside = c < S->ncols;
   int nl = -1;  // >= 1: sunlit column with snow, goes through SNICAR with nl layers

@@ -539,7 +539,10 @@ __device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const La
 
 // One workgroup counts CF_COUNT_TILES tiles of 256 columns (a tile = one workgroup of k_cf_init) and takes the
 // slices of all of them with ONE atomic per class: the class totals are 12 addresses, every atomic on them serialises.
-constexpr int CF_COUNT_TILES = 8;
+#ifndef CF_COUNT_TILES_N
+#define CF_COUNT_TILES_N 4
+#endif
+constexpr int CF_COUNT_TILES = CF_COUNT_TILES_N;
 __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S)
 {
   __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];

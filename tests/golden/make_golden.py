@@ -88,18 +88,19 @@ def stack(steps, rows):
     return out
 
 
-def convert_module(mod):
+def convert_module(mod, src=REF_DATA, dst=HERE):
     data = {}
-    steps_in, cin = parse_blocks(os.path.join(REF_DATA, mod + "_IN.txt"))
-    steps_out, cout = parse_blocks(os.path.join(REF_DATA, mod + "_OUT.txt"))
+    steps_in, cin = parse_blocks(os.path.join(src, mod + "_IN.txt"))
+    steps_out, cout = parse_blocks(os.path.join(src, mod + "_OUT.txt"))
     assert steps_in == steps_out, mod
     data["steps"] = np.array(steps_in, dtype=np.int64)
     for label, rows in cin.items():
         data["in/" + label] = stack(steps_in, rows)
     for label, rows in cout.items():
         data["out/" + label] = stack(steps_out, rows)
-    np.savez_compressed(os.path.join(HERE, mod + ".npz"), **data)
-    print(f"{mod}: {len(steps_in)} steps, {len(cin)} in / {len(cout)} out labels")
+    os.makedirs(dst, exist_ok=True)
+    np.savez_compressed(os.path.join(dst, mod + ".npz"), **data)
+    print(f"{mod}: {len(steps_in)} steps, {len(cin)} in / {len(cout)} out labels -> {os.path.relpath(dst, HERE) or '.'}")
 
 
 def convert_snowoptics():
@@ -126,6 +127,10 @@ def main():
         sys.exit("reference data not mounted; the committed .npz files are the fixtures")
     for m in MODULES:
         convert_module(m)
+    # test/new_data: a second ELM dump of the same site under different (snow-free, summer) forcing that no reference test
+    # reads; same format, converted the same way into tests/golden/newdata/
+    for m in MODULES:
+        convert_module(m, REF_DATA.replace("/data", "/new_data"), os.path.join(HERE, "newdata"))
     convert_snowoptics()
     convert_pft()
     if args.ref:

@@ -375,7 +375,7 @@ def _fixture_device_state(module, rows, pft, optics, **scalars):
     return D, oin, fout
 
 
-def test_canopy_fluxes_fixture_on_device():
+def test_canopy_fluxes_fixture_on_device(min_total=8633, max_loose=120, both_day_and_night=True):
     """The reference's CanopyFluxes fixture (test/test_CanFlux.cc, test/data/CanopyFluxes_{IN,OUT}.txt, 97 steps, 50 by day
     and 47 by night) through the HIP kernels: driven as the reference's test drives the physics - ELM's own forc_rho /
     forc_po2 / forc_pco2 handed in (elmk_canopy_fluxes_given; ELM ran 397.84 ppm CO2, the wrapper hard-wires 355) and the
@@ -413,7 +413,8 @@ def test_canopy_fluxes_fixture_on_device():
             total += ok.size
             nloose += int((~ok).sum())
             if not ok.all():
-                worst = max(worst, float(np.where(ok, 0.0, F.rel_err(got, exp, floor=1e-18)).max()))
+                # (relative to the field's own scale: a difference of 4e-16 on an h2ocan of 1e-16 is not an error of 100 %)
+                worst = max(worst, float(np.where(ok, 0.0, np.abs(got - exp)).max()) / max(float(np.nanmax(np.abs(exp))), 1e-300))
             ref = np.ascontiguousarray(S[name].reshape(len(sub), -1))
             if ref.dtype.kind == "f":
                 assert ((got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))).all(), name
@@ -423,8 +424,18 @@ def test_canopy_fluxes_fixture_on_device():
         assert trips.min() >= 3 and trips.max() <= 41
         nday += int((d["in/parsun_z"][sub].reshape(len(sub), -1)[:, 0] > 0).sum())
         D.close()
-    assert total >= 8633 and nloose <= 120 and worst < 1e-9, (total, nloose, worst)
-    assert 0 < nday < len(rows)  # both the day branch (root finds) and the night branch ran
+    assert total >= min_total and nloose <= max_loose and worst < 1e-9, (total, nloose, worst)
+    assert 0 < nday and (nday < len(rows) or not both_day_and_night)  # the day branch (root finds) and, in the first dump, the night branch ran
+
+
+def test_second_fixture_dump_on_device():
+    """The reference's second ELM dump, test/new_data (tests/golden/newdata/, read by no reference test; snow-free summer
+    forcing, 97 steps per module) through the HIP kernels: the five streaming modules against the _OUT records, and
+    CanopyFluxes as above (a bounded set beyond 1e-15, all < 1e-9, bit-identical to the oracle).  The oracle is pinned
+    against the same vectors on the CPU (tests/test_oracle_golden_newdata.py)."""
+    with F.dataset("newdata"):
+        test_fixture_steps_on_device()
+        test_canopy_fluxes_fixture_on_device(min_total=23000, max_loose=150, both_day_and_night=False)
 
 
 def test_bareground_fluxes_fixture_on_device():

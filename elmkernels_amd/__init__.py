@@ -9,7 +9,9 @@ mirror of that interface; see DESIGN.md.
 from .decomp import all_ranges, block_range  # noqa: F401
 from .state import (  # noqa: F401
     KERNEL_NAMES,
+    ELMInterface,
     ELMState,
+    initialize_kokkos_elm,
     kokkos_albedo_snicar,
     kokkos_bareground_fluxes,
     kokkos_canopy_fluxes,

@@ -402,3 +402,54 @@ def advance_physics(S, dt):
 def timestep7(S, dt):
     """The seven calls of ELMInterface::advance (driver/kokkos/elm_kokkos_interface.cc:289-307), in order."""
     S._chk(S.lib.elmk_timestep7(S.ctx, float(dt)), "timestep7")
+
+
+class ELMInterface:
+    """Python mirror of the reference's driver class ELM::ELMInterface (driver/kokkos/elm_kokkos_interface.hh:11-28,
+    elm_kokkos_interface.cc:38-358) above the C ABI, the counterpart of include/elmk_interface.hpp: same member names, same call
+    order in advance(), same PrimaryVars members (src/data/elm_state.h:17-48).  File reads and date arithmetic stay with
+    the caller, who uploads fields / forcing records and passes the interpolation weights."""
+
+    PRIMARY_VARS = ("snl", "snow_depth", "frac_sno", "int_snow", "snw_rds", "h2osoi_liq", "h2osoi_ice", "h2osoi_vol", "h2ocan",
+                    "h2osno", "h2osfc", "t_soisno", "t_grnd", "t_h2osfc", "t_h2osfc_bef", "nrad", "dz", "zsoi", "zisoi")
+
+    def __init__(self, ncols, device=0):
+        self.S = ELMState(ncols, device=device)
+        self.conservation = None
+
+    def setup(self, land, scalars, pft, snicar, soilcolor, snow_age_tables, init_params=None, graph=True):
+        """ELMInterface::setup (elm_kokkos_interface.cc:58-267) minus the file reads."""
+        S = self.S
+        S.set_land(**land)
+        S.set_scalars(**scalars)
+        S.set_pft(pft)
+        S.set_snicar(snicar)
+        S.set_soilcolor(*soilcolor)
+        S.set_snow_age_tables(snow_age_tables)
+        if init_params is not None:
+            S.set_init_params(*init_params)
+        S.set_graph(bool(graph))
+
+    def initialize(self):
+        """The per-column part of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428), after the uploads."""
+        initialize_kokkos_elm(self.S)
+
+    def advance(self, dt_seconds, forc_wt1, forc_wt2, month_wt1, month_wt2, qbot_is_rh=False):
+        """ELMInterface::advance (elm_kokkos_interface.cc:269-322); returns False like the reference."""
+        S = self.S
+        compute_phenology(S, month_wt1, month_wt2)
+        get_forcing(S, forc_wt1, forc_wt2, qbot_is_rh)
+        kokkos_init_timestep(S)
+        advance_physics(S, dt_seconds)
+        self.conservation = kokkos_evaluate_conservation(S, dt_seconds)
+        flags, col = S.error_summary()
+        if flags & 0xC7FF:  # ELMK_ERR_FATAL_MASK
+            raise RuntimeError(f"ELM physics error flags {flags:#x}, first at column {col}")
+        return False
+
+    def getPrimaryVars(self):
+        """ELMInterface::getPrimaryVars / copyPrimaryVars (:324-356): the PrimaryVars members as host arrays."""
+        return {k: self.S[k] for k in self.PRIMARY_VARS}
+
+    def close(self):
+        self.S.close()

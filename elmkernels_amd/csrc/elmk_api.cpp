@@ -1038,17 +1038,22 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
 
 int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_per_s)
 {
+  return elmk_copy_bandwidth_shape(ctx, bytes, iters, 0, gbytes_per_s);
+}
+
+int elmk_copy_bandwidth_shape(elmk_ctx* ctx, int64_t bytes, int iters, int shape, double* gbytes_per_s)
+{
   if (int rc = enter(ctx)) return rc;
-  if (bytes < 8 || iters <= 0 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
-  const int64_t n = bytes / 8;
+  if (bytes < 64 || iters <= 0 || shape < 0 || shape > 3 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
+  const int64_t n = (bytes / 64) * 8;  // whole 64-byte runs: every shape copies the same bytes
   DevBuf a, b;
   if (hip_fail(ctx, a.alloc((size_t)n * 8), "hipMalloc") || hip_fail(ctx, b.alloc((size_t)n * 8), "hipMalloc")) return ELMK_E_NOMEM;
   EventList ev;
   HIPCHK(ev.create(2));
   HIPCHK(hipMemsetAsync(a.p, 0, (size_t)n * 8, ctx->stream));
-  launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream);  // warm-up
+  launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream, shape);  // warm-up
   HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  for (int i = 0; i < iters; i++) launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream);
+  for (int i = 0; i < iters; i++) launch_copy((const double*)a.p, (double*)b.p, n, ctx->stream, shape);
   HIPCHK(hipEventRecord(ev[1], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;

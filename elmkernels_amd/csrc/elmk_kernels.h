@@ -62,7 +62,7 @@ void launch_fill(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, do
 void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, int64_t nbase, uint64_t seed,
                  int field_id, int mode, double amp, hipStream_t st);
 void launch_flag_reduce(const uint32_t* flags, int64_t n, uint32_t* or_out, long long* first_bad, hipStream_t st);
-void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st);
+void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st, int shape = 0);
 void launch_math_eval(int fn, const double* x, const double* y, double* out, int64_t n, hipStream_t st);
 
 }  // namespace elmk

@@ -23,6 +23,10 @@
 #include "elmk_stream.h"
 #include "elmk_albedo_col.h"
 
+#ifndef CF_PROBE
+#define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
+#endif
+
 namespace elmk {
 
 
@@ -124,12 +128,23 @@ struct CiCtx {
   bool c3flag;
   double gs_mol, ac, aj, ap, ag, an;
   uint32_t err;
+#if CF_PROBE >= 4
+  uint32_t nev;            // probe only: ci_func evaluations of this lane
+  uint32_t* wev;           // probe only: this wave's count of executed ci_func bodies (LDS)
+#endif
 };
 
 // photosynthesis_impl.hh:308-390
 __device__ __forceinline__ double ci_func(double ci, CiCtx& k)
 {
   const double theta_ip = 0.95;
+#if CF_PROBE >= 4
+  k.nev += 1u;
+  {
+    const unsigned long long m_ = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) *k.wev += 1u;
+  }
+#endif
   if (k.c3flag) {
     k.ac = k.vcmax_z * dmax(ci - k.cp, 0.0) / (ci + k.kc_o);
     k.aj = k.je * dmax(ci - k.cp, 0.0) / (4.0 * ci + 8.0 * k.cp);
@@ -365,7 +380,11 @@ struct PsnSolveIn {
 };
 __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const PsnPhaseIn& q, int nrad, double forc_pbot,
                                                   double esat_tv, double eair, double oair, double cair, double rb,
-                                                  double btran, double par_z, double lai_z, uint32_t& err)
+                                                  double btran, double par_z, double lai_z, uint32_t& err
+#if CF_PROBE >= 4
+                                                  , uint32_t* pr_wev, uint32_t& pr_nev
+#endif
+)
 {
   if (nrad <= 0) return 0.0;  // laican == 0 -> rs = 0 (:266-281)
   const double fnps = 0.15;
@@ -410,7 +429,14 @@ __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const Psn
     k.gs_mol = 0.0;
     k.ac = k.aj = k.ap = k.ag = k.an = 0.0;
     k.err = 0;
+#if CF_PROBE >= 4
+    k.nev = 0u;
+    k.wev = pr_wev;
+#endif
     psn_hybrid(ci0, k);
+#if CF_PROBE >= 4
+    pr_nev += k.nev;
+#endif
     err |= k.err;
     double gs_mol = k.gs_mol;
     const double an = k.an;
@@ -447,9 +473,6 @@ __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const Psn
 //                it converges, stores the converged state at the queue position and takes the next position
 //   k_cf_finish  coalesced, one thread per column: compute_flux (:456-540), the 2 m profile, state writes
 // =====================================================================================================
-#ifndef CF_PROBE
-#define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
-#endif
 constexpr int CF_REFILL_MIN = 8;
 #ifndef CF_PRIO_TRIPS
 #define CF_PRIO_TRIPS 10  // trips after which a column makes its wave a priority wave (k_cf_iterate)
@@ -930,8 +953,17 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
   const uint64_t pr_t0 = wall_clock64();
   uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0, pr_brent = 0, pr_brent_trips = 0, pr_c4 = 0, pr_day = 0;
 #endif
+#if CF_PROBE >= 4
+  __shared__ uint32_t s_wev[2][CF_ITER_THREADS / 64];  // wave-level ci_func executions, [phase][wave]
+  if (lane == 0) s_wev[0][threadIdx.x >> 6] = s_wev[1][threadIdx.x >> 6] = 0u;
+  uint32_t pr_nev_sun = 0u, pr_nev_sha = 0u;  // per-lane ci_func evaluations
+  uint64_t pr_daytrips = 0;                   // wave-trips with at least one day lane
+#define PR_SOLVE_ARGS(ph, acc) , &s_wev[ph][threadIdx.x >> 6], acc
+#else
+#define PR_SOLVE_ARGS(ph, acc)
+#endif
 #if CF_PROBE == 5  // shader-clock cycles per section of the loop (wave-uniform accumulators)
-  uint64_t pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t pr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t pr_last = clock64();
 #define PR_T(i)                    \
   {                                \
@@ -1114,6 +1146,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       const double raw1 = rah1;
       const double svpts = el;
       const double eah = C(forc_pbot) * qaf / 0.622;
+      PR_T(2)
 
       double rssun, rssha;
       {
@@ -1154,19 +1187,20 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
           forc_po2 = grec[REC_forc_po2 * 8];
           forc_pco2 = grec[REC_forc_pco2 * 8];
         }
-        PR_T(2)
-        rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
-                                C(lai_sun_z), err);
         PR_T(3)
+        rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
+                                C(lai_sun_z), err PR_SOLVE_ARGS(0, pr_nev_sun));
+        PR_T(4)
         rssha = psn_phase_solve(J, qsha, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sha, C(parsha),
-                                C(lai_sha_z), err);
+                                C(lai_sha_z), err PR_SOLVE_ARGS(1, pr_nev_sha));
       }
-      PR_T(4)
+      PR_T(5)
 #if CF_PROBE >= 4
       pr_brent += (uint64_t)__popcll(__ballot((err & 0x80000000u) != 0u));
       pr_brent_trips += (__ballot((err & 0x80000000u) != 0u) != 0ull) ? 1u : 0u;
       pr_c4 += (__ballot(!c3flag) != 0ull) ? 1u : 0u;
       pr_day += (uint64_t)__popcll(__ballot(day));
+      pr_daytrips += (__ballot(day) != 0ull) ? 1u : 0u;
       err &= 0x7FFFFFFFu;
 #endif
 
@@ -1256,6 +1290,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       const double ecidif = dmax(0.0, qflx_evap_veg - qflx_tran_veg - h2ocan_dt);
       qflx_evap_veg = dmin(qflx_evap_veg, qflx_tran_veg + h2ocan_dt);
       const double eflx_sh_veg = efsh + dc1 * wtga * dt_veg + errv + erre + HVAP * ecidif;
+      PR_T(6)
       double deldT;
       qsat(t_veg, C(forc_pbot), el, deldT, qsatl, qsatldT);
 
@@ -1291,7 +1326,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       }
       if (itlef > 40) stop = true;  // itmax: while (itlef <= itmax && !stop)
 
-      PR_T(5)
+      PR_T(7)
       // ---------------- converged: hand the state to k_cf_finish, release the lane ----------------
       if (stop) {
         const gptr<double> fin = S->cf_fin + CF_FIN_BASE(pos);
@@ -1321,18 +1356,28 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
         fin[FIN_err * 8] = (double)err;
         pos = -1;
       }
-      PR_T(6)
+      PR_T(8)
 #if CF_PROBE >= 4
       pr_cols += (uint64_t)__popcll(__ballot(stop));
 #endif
     }
   }
 #if CF_PROBE >= 4
+  uint64_t pr_nev_sun_w = pr_nev_sun, pr_nev_sha_w = pr_nev_sha;  // wave sums of the per-lane evaluation counts
+  for (int off = 32; off; off >>= 1) {
+    pr_nev_sun_w += __shfl_xor(pr_nev_sun_w, off, 64);
+    pr_nev_sha_w += __shfl_xor(pr_nev_sha_w, off, 64);
+  }
   if (lane == 0) {
-    const gptr<double> o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    const gptr<double> o = S->wk + (int64_t)WK_DEBUG * ld + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
 #if CF_PROBE == 5
-    for (int i = 0; i < 4; i++) o[8 + i] = (double)(pr_acc[2 * i] + pr_acc[2 * i + 1]);
+    for (int i = 0; i < 12; i++) o[16 + i] = (double)pr_acc[i];
 #endif
+    o[8] = (double)pr_daytrips;
+    o[28] = (double)pr_nev_sun_w;
+    o[29] = (double)pr_nev_sha_w;
+    o[30] = (double)s_wev[0][threadIdx.x >> 6];
+    o[31] = (double)s_wev[1][threadIdx.x >> 6];
     o[0] = (double)pr_t0;
     o[1] = (double)pr_texh;
     o[2] = (double)wall_clock64();

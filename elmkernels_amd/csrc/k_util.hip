@@ -193,9 +193,41 @@ __global__ __launch_bounds__(256) void k_copy(const double* __restrict__ src, do
   if (i < n) dst[i] = src[i];
 }
 
-void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st)
+// The same copy in other access shapes (elmk_copy_bandwidth_shape): what bounds a streaming kernel on this chip is how many
+// bytes a CU keeps in flight, and that is (bytes per load) x (independent loads per wave) x (resident waves).
+//   shape 1: 16 bytes per lane, one load per thread          (the float4 copy the 6.29 TB/s figure was measured with)
+//   shape 2:  8 bytes per lane, four independent loads per thread, each a contiguous 512-byte run per wave
+//   shape 3: 16 bytes per lane, four independent loads per thread
+__global__ __launch_bounds__(256) void k_copy16(const double2* __restrict__ src, double2* __restrict__ dst, int64_t n2)
 {
-  if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) dst[i] = src[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_x4(const T* __restrict__ src, T* __restrict__ dst, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x * 4) + threadIdx.x;
+  if (i + 3 * 256 < n) {
+    const T a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    dst[i] = a;
+    dst[i + 256] = b;
+    dst[i + 512] = c;
+    dst[i + 768] = d;
+  } else {
+    for (int k = 0; k < 4; k++)
+      if (i + k * 256 < n) dst[i + k * 256] = src[i + k * 256];
+  }
+}
+
+void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st, int shape)
+{
+  if (n <= 0) return;
+  switch (shape) {
+    case 1: hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, (const double2*)src, (double2*)dst, n / 2); break;
+    case 2: hipLaunchKernelGGL(k_copy_x4<double>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, dst, n); break;
+    case 3: hipLaunchKernelGGL(k_copy_x4<double2>, dim3((unsigned)((n / 2 + 1023) / 1024)), dim3(256), 0, st, (const double2*)src, (double2*)dst, n / 2); break;
+    default: hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

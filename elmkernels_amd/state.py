@@ -247,9 +247,10 @@ class ELMState:
         """timestep7 as one replayed HIP graph (elmk_set_graph)."""
         self._chk(self.lib.elmk_set_graph(self.ctx, int(bool(on))), "set_graph")
 
-    def copy_bandwidth(self, nbytes=1 << 30, iters=20):
+    def copy_bandwidth(self, nbytes=1 << 30, iters=20, shape=0):
+        """device-to-device copy rate in GB/s (read + write bytes); shape: see elmk_copy_bandwidth_shape"""
         g = C.c_double()
-        self._chk(self.lib.elmk_copy_bandwidth(self.ctx, int(nbytes), int(iters), C.byref(g)), "copy_bandwidth")
+        self._chk(self.lib.elmk_copy_bandwidth_shape(self.ctx, int(nbytes), int(iters), int(shape), C.byref(g)), "copy_bandwidth")
         return g.value
 
 

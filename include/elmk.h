@@ -233,9 +233,10 @@ int elmk_soil_temperature(elmk_ctx *ctx, double dt);
  * prune_snow_layers, update_aerosol_mass_and_concen, snow_aging - five launches in the reference, one pass per column here.
  * Updates snl and the snow mesh (dz, zsoi, zisoi, t_soisno, h2osoi_ice/liq of the snow levels and of the top soil level),
  * snw_rds, the aerosol masses mss_* and concentrations cnc_*, h2osno, snow_depth, frac_sno(_eff), int_snow, qflx_snow_melt,
- * qflx_top_soil, qflx_sl_top_soil, qflx_snow2topsoi, mflx_*, qflx_rootsoi.  PARITY UNPINNED against the reference (it has
- * no fixture for this path and its header does not build without netcdf); see ELMK_WARN_SNOW_* for the two places where
- * the reference's own result is undefined. */
+ * qflx_top_soil, qflx_sl_top_soil, qflx_snow2topsoi, mflx_*, qflx_rootsoi.  The reference has no fixture for this path; the
+ * checker behind the parity tests is pinned bit for bit by the reference's own snow_hydrology_impl.hh for every function
+ * but snow_aging and the two aerosol bookkeeping functions (those: parity unpinned).  See ELMK_WARN_SNOW_* for the two
+ * places where the reference's own result is undefined. */
 int elmk_snow_hydrology(elmk_ctx *ctx, double dt);
 /* kokkos_surface_fluxes(S, dt) (surface_fluxes_kokkos.cc:5-107): flux corrections for the new ground temperature,
  * ground heat flux, total fluxes, dew / sublimation partition, outgoing longwave, soil energy balance */
@@ -315,6 +316,10 @@ int elmk_read_scratch(elmk_ctx *ctx, int kind, void *host, int64_t offset, int64
 /* device-to-device copy bandwidth probe (read+write bytes / s) on this context's device, used as the
  * empirical HBM line next to the 8 TB/s datasheet peak */
 int elmk_copy_bandwidth(elmk_ctx *ctx, int64_t bytes, int iters, double *gbytes_per_s);
+/* the same probe in a chosen access shape: 0 = 8 bytes per lane, one load per thread (the shape of elmk_copy_bandwidth and of
+ * the snapshot restore); 1 = 16 bytes per lane; 2 = 8 bytes per lane, four independent loads per thread; 3 = 16 bytes per
+ * lane, four independent loads per thread.  bench.py reports the best of them as roofline.empirical_peak. */
+int elmk_copy_bandwidth_shape(elmk_ctx *ctx, int64_t bytes, int iters, int shape, double *gbytes_per_s);
 /* Evaluate one function of elmkernels_amd/csrc/elmk_math.h - the device restatement of the host libm's exp / log / log10 /
  * pow / atan / tanh / cos / erf / acos / expm1 (the <cmath> calls of src/physics headers) - on n host values: out[i] = fn(x[i]) or pow(x[i], y[i]).
  * ELMK_MATH_SQRT and ELMK_MATH_DIV (x[i] / y[i]) are the device's own IEEE operations, included so that the tests can

@@ -234,8 +234,15 @@ void elmo_canopy_fluxes_given(elmo_state *S, double dt, const double *rho_in, co
 void elmo_bareground_fluxes_given(elmo_state *S, const double *rho_in);
 void elmo_albedo_snicar_ex(elmo_state *S, double *fabd_sun_out, double *fabd_sha_out);
 /* kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188; ELMInterface::advance :313, between soil_temperature and
- * surface_fluxes); elmo_physics_g.c.  PARITY UNPINNED (see that file's header). */
+ * surface_fluxes); elmo_physics_g.c, whose header says what is pinned bit for bit by the reference's own functions (all the
+ * snow functions but snow_aging) and what is not (snow_aging, the two aerosol bookkeeping functions). */
 void elmo_snow_hydrology(elmo_state *S, double dt);
+/* the same wrapper one stage at a time (0..ELMO_SNOW_HYDROLOGY_STAGES-1 in the wrapper's order: snow_water, aerosol
+   deposition, aerosol_phase_change, transpiration, snow_compaction, combine_layers, divide_layers, prune_snow_layers,
+   aerosol mass / concentration, snow_aging), over all columns: lets a test put the reference's own function of a stage
+   (oracle/ref_harness_snow.cc) on the inputs the restatement's stage saw */
+#define ELMO_SNOW_HYDROLOGY_STAGES 10
+void elmo_snow_hydrology_stage(elmo_state *S, double dt, int stage);
 /* the "init functions" lambda of ELM::initialize_kokkos_elm (initialize_elm_kokkos.cc:373-428); elmo_physics_h.c */
 void elmo_initialize_state(elmo_state *S);
 void elmo_set_init_params(elmo_state *S, double organic_max, const double *roota_par, const double *rootb_par);

@@ -453,43 +453,84 @@ void elmo_soil_temperature(elmo_state *S, double dt) { elmo_soil_temperature_ex(
 /* snow_hydrology_kokkos.cc:23-188: snow_water; compute_aerosol_deposition; aerosol_phase_change, transpiration,
  * snow_compaction, combine_layers, divide_layers, prune_snow_layers; update_aerosol_mass_and_concen; snow_aging - five
  * parallel_for launches in the reference, one pass per column here (a column only reads what the same column wrote) */
+/* One call of the wrapper per value of `stage` (0..9, in the wrapper's order), over all columns: what
+   elmo_snow_hydrology does, cut where the reference's own functions begin and end, so that tests can run the reference's
+   function of one stage (oracle/ref_harness_snow.cc) on exactly the inputs the restatement's stage saw.
+     0 snow_water  1 aerosol deposition  2 aerosol_phase_change  3 transpiration  4 snow_compaction  5 combine_layers
+     6 divide_layers  7 prune_snow_layers  8 aerosol mass and concentration  9 snow_aging */
+static void snow_hydrology_stage_col(elmo_state *S, double dt, int64_t c, int stage, uint32_t *err)
+{
+  switch (stage) {
+    case 0:
+      elmo_snow_water(S->do_capsnow[c], S->snl[c], dt, S->frac_sno_eff[c], S->h2osno[c], S->qflx_sub_snow[c],
+                      S->qflx_evap_grnd[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c], S->qflx_rain_grnd[c], S->qflx_snomelt[c],
+                      &S->qflx_snow_melt[c], &S->qflx_top_soil[c], &S->int_snow[c], &S->frac_sno[c], &S->mflx_neg_snow[c],
+                      LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5),
+                      LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5), LV(dz, 20), err);
+      break;
+    case 1: {
+      const double aer[11] = {S->aer_bcphi[c],  S->aer_bcpho[c],  S->aer_bcdep[c],  S->aer_dst1_1[c], S->aer_dst1_2[c], S->aer_dst2_1[c],
+                              S->aer_dst2_2[c], S->aer_dst3_1[c], S->aer_dst3_2[c], S->aer_dst4_1[c], S->aer_dst4_2[c]};
+      elmo_aerosol_deposition(dt, S->snl[c], aer, LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5),
+                              LV(mss_dst3, 5), LV(mss_dst4, 5));
+      break;
+    }
+    case 2:
+      elmo_aerosol_phase_change(S->snl[c], dt, S->qflx_sub_snow[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5),
+                                LV(mss_bcpho, 5));
+      break;
+    case 3: elmo_transpiration(S->veg_active[c], S->qflx_tran_veg[c], LV(rootr, 15), LV(qflx_rootsoi, 15)); break;
+    case 4:
+      elmo_snow_compaction(S->snl[c], S->land.ltype, dt, S->int_snow[c], S->n_melt[c], S->frac_sno[c], LV(imelt, 20),
+                           LV(swe_old, 5), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(frac_iceold, 20),
+                           LV(dz, 20));
+      break;
+    case 5:
+      elmo_combine_layers(S->land.urbpoi, S->land.ltype, dt, &S->snl[c], &S->h2osno[c], &S->snow_depth[c], &S->frac_sno_eff[c],
+                          &S->frac_sno[c], &S->int_snow[c], &S->qflx_sl_top_soil[c], &S->qflx_snow2topsoi[c],
+                          &S->mflx_snowlyr_col[c], LV(t_soisno, 20), LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(snw_rds, 5),
+                          LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5),
+                          LV(mss_dst4, 5), LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), err);
+      break;
+    case 6:
+      elmo_divide_layers(S->frac_sno[c], &S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(snw_rds, 5),
+                         LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5),
+                         LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), err);
+      break;
+    case 7:
+      elmo_prune_snow_layers(S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(dz, 20), LV(zsoi, 20),
+                             LV(zisoi, 21));
+      break;
+    case 8: {
+      double *const mss[6] = {LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5)};
+      double *const cnc[6] = {LV(cnc_bcphi, 5), LV(cnc_bcpho, 5), LV(cnc_dst1, 5), LV(cnc_dst2, 5), LV(cnc_dst3, 5), LV(cnc_dst4, 5)};
+      elmo_aerosol_mass_and_concen(dt, S->snl[c], S->do_capsnow[c], S->qflx_snwcp_ice[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20),
+                                   mss, cnc);
+      break;
+    }
+    default:
+      elmo_snow_aging(S->do_capsnow[c], S->snl[c], S->frac_sno[c], dt, S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c], S->h2osno[c],
+                      LV(dz, 20), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(qflx_snofrz_lyr, 5),
+                      S->snowage[0], S->snowage[1], S->snowage[2], LV(snw_rds, 5), err);
+  }
+}
+
+void elmo_snow_hydrology_stage(elmo_state *S, double dt, int stage)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < S->ncols; c++) {
+    uint32_t err = 0;
+    snow_hydrology_stage_col(S, dt, c, stage, &err);
+    S->err_flags[c] |= err;
+  }
+}
+
 void elmo_snow_hydrology(elmo_state *S, double dt)
 {
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < S->ncols; c++) {
     uint32_t err = 0;
-    elmo_snow_water(S->do_capsnow[c], S->snl[c], dt, S->frac_sno_eff[c], S->h2osno[c], S->qflx_sub_snow[c],
-                    S->qflx_evap_grnd[c], S->qflx_dew_snow[c], S->qflx_dew_grnd[c], S->qflx_rain_grnd[c], S->qflx_snomelt[c],
-                    &S->qflx_snow_melt[c], &S->qflx_top_soil[c], &S->int_snow[c], &S->frac_sno[c], &S->mflx_neg_snow[c],
-                    LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5),
-                    LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5), LV(dz, 20), &err);
-    const double aer[11] = {S->aer_bcphi[c],  S->aer_bcpho[c],  S->aer_bcdep[c],  S->aer_dst1_1[c], S->aer_dst1_2[c], S->aer_dst2_1[c],
-                            S->aer_dst2_2[c], S->aer_dst3_1[c], S->aer_dst3_2[c], S->aer_dst4_1[c], S->aer_dst4_2[c]};
-    elmo_aerosol_deposition(dt, S->snl[c], aer, LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5),
-                            LV(mss_dst3, 5), LV(mss_dst4, 5));
-    elmo_aerosol_phase_change(S->snl[c], dt, S->qflx_sub_snow[c], LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(mss_bcphi, 5),
-                              LV(mss_bcpho, 5));
-    elmo_transpiration(S->veg_active[c], S->qflx_tran_veg[c], LV(rootr, 15), LV(qflx_rootsoi, 15));
-    elmo_snow_compaction(S->snl[c], S->land.ltype, dt, S->int_snow[c], S->n_melt[c], S->frac_sno[c], LV(imelt, 20),
-                         LV(swe_old, 5), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(frac_iceold, 20),
-                         LV(dz, 20));
-    elmo_combine_layers(S->land.urbpoi, S->land.ltype, dt, &S->snl[c], &S->h2osno[c], &S->snow_depth[c], &S->frac_sno_eff[c],
-                        &S->frac_sno[c], &S->int_snow[c], &S->qflx_sl_top_soil[c], &S->qflx_snow2topsoi[c],
-                        &S->mflx_snowlyr_col[c], LV(t_soisno, 20), LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(snw_rds, 5),
-                        LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5),
-                        LV(mss_dst4, 5), LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), &err);
-    elmo_divide_layers(S->frac_sno[c], &S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(snw_rds, 5),
-                       LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5),
-                       LV(dz, 20), LV(zsoi, 20), LV(zisoi, 21), &err);
-    elmo_prune_snow_layers(S->snl[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20), LV(t_soisno, 20), LV(dz, 20), LV(zsoi, 20),
-                           LV(zisoi, 21));
-    double *const mss[6] = {LV(mss_bcphi, 5), LV(mss_bcpho, 5), LV(mss_dst1, 5), LV(mss_dst2, 5), LV(mss_dst3, 5), LV(mss_dst4, 5)};
-    double *const cnc[6] = {LV(cnc_bcphi, 5), LV(cnc_bcpho, 5), LV(cnc_dst1, 5), LV(cnc_dst2, 5), LV(cnc_dst3, 5), LV(cnc_dst4, 5)};
-    elmo_aerosol_mass_and_concen(dt, S->snl[c], S->do_capsnow[c], S->qflx_snwcp_ice[c], LV(h2osoi_ice, 20), LV(h2osoi_liq, 20),
-                                 mss, cnc);
-    elmo_snow_aging(S->do_capsnow[c], S->snl[c], S->frac_sno[c], dt, S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c], S->h2osno[c],
-                    LV(dz, 20), LV(h2osoi_liq, 20), LV(h2osoi_ice, 20), LV(t_soisno, 20), LV(qflx_snofrz_lyr, 5),
-                    S->snowage[0], S->snowage[1], S->snowage[2], LV(snw_rds, 5), &err);
+    for (int stage = 0; stage < ELMO_SNOW_HYDROLOGY_STAGES; stage++) snow_hydrology_stage_col(S, dt, c, stage, &err);
     S->err_flags[c] |= err;
   }
 }

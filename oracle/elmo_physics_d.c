@@ -8,12 +8,15 @@
  *   src/physics/pentadiagonal_solver_impl.hh      src/physics/phase_change_impl.hh
  *
  * Pinning: the reference has no fixture for this path.  soil_thermal_properties.h, pentadiagonal_solver.h and
- * phase_change.h compile here and are run against these restatements bit for bit (tests/test_oracle_vs_ref.py).
- * soil_temperature.h, soil_temp_rhs.h and soil_temp_lhs.h do not compile without Kokkos (they include
- * invoke_kernel.hh, whose serial branch references a function that only exists under ENABLE_KOKKOS), so the
- * functions restated from them - surface heat flux, diffusive flux, matrix factor, RHS / LHS assembly, temperature
- * update - are PARITY UNPINNED against the reference; tests check them through the residual of the assembled system
- * and the column energy balance instead.
+ * phase_change.h compile here as shipped and are run against these restatements bit for bit (tests/test_oracle_vs_ref.py).
+ * soil_temperature.h, soil_temp_rhs.h and soil_temp_lhs.h include invoke_kernel.hh, whose serial branch names a function
+ * that is only defined under ENABLE_KOKKOS; with ONE declaration of that name in front of the includes (the reference's own
+ * entity, no body, never instantiated: oracle/ref_harness_soil.cc) they compile, and the WHOLE wrapper - surface heat
+ * fluxes, diffusive fluxes, matrix factor, soil_temp::detail::get_rhs_* / get_matrix_* / assemble_*, solve, temperature
+ * update, phase change, ground temperature - is run by the reference's own per-column functions against
+ * elmo_soil_temperature: right-hand side, banded matrix, heat fluxes and every state field BIT FOR BIT, also chained and with
+ * ponded water / melting packs (test_soil_temperature_whole_wrapper_bitwise).  The structural tests
+ * (tests/test_soil_temperature_oracle.py) stay as a second, reference-free check.
  */
 #include <math.h>
 

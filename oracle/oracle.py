@@ -73,6 +73,7 @@ class _Lib:
         L.elmo_albedo_snicar_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elmo_soil_temperature.argtypes = [C.c_void_p, C.c_double]
         L.elmo_snow_hydrology.argtypes = [C.c_void_p, C.c_double]
+        L.elmo_snow_hydrology_stage.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.elmo_initialize_state.argtypes = [C.c_void_p]
         L.elmo_set_init_params.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.elmo_soil_temperature_ex.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 5
@@ -108,6 +109,16 @@ class _Lib:
             if hasattr(R, "elmref_get_forcing"):
                 R.elmref_get_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                 R.elmref_phenology.argtypes = [C.c_void_p, C.c_double, C.c_double]
+
+
+        # the reference's snow-hydrology and soil-temperature functions: one library each (oracle/Makefile says why)
+        self.ref_snow = _load(os.path.join(HERE, "_ref", "libelmref_snow.so"))
+        if self.ref_snow is not None:
+            self.ref_snow.elmref_snow_hydrology_stage.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+            self.ref_snow.elmref_snow_hydrology_stage.restype = C.c_int
+        self.ref_soil = _load(os.path.join(HERE, "_ref", "libelmref_soil.so"))
+        if self.ref_soil is not None:
+            self.ref_soil.elmref_soil_temperature.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 3
 
 
 _LIB = None
@@ -274,8 +285,31 @@ class OracleState:
         return out
 
     def snow_hydrology(self, dt):
-        """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188); parity unpinned (oracle/elmo_physics_g.c)."""
+        """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188); oracle/elmo_physics_g.c says what pins it."""
         self._L.lib.elmo_snow_hydrology(self.ptr, float(dt))
+
+    SNOW_STAGES = ("snow_water", "aerosol_deposition", "aerosol_phase_change", "transpiration", "snow_compaction",
+                   "combine_layers", "divide_layers", "prune_snow_layers", "aerosol_mass_and_concen", "snow_aging")
+    SNOW_STAGES_REF = (0, 2, 3, 4, 5, 6, 7)  # the stages the reference's own functions can run here (ref_harness_snow.cc)
+
+    def snow_hydrology_stage(self, dt, stage, ref=False, skip=None):
+        """One stage of the wrapper over all columns; ref=True: the reference's own function (columns with skip != 0 untouched).
+        Returns the number of columns in which the reference threw (0 for the restatement)."""
+        if not ref:
+            self._L.lib.elmo_snow_hydrology_stage(self.ptr, float(dt), int(stage))
+            return 0
+        sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+        n = self._L.ref_snow.elmref_snow_hydrology_stage(self.ptr, float(dt), int(stage), None if sk is None else sk.ctypes.data)
+        assert n >= 0, "stage has no reference run"
+        return n
+
+    def soil_temperature_ref(self, dt):
+        """kokkos_soil_temperature by the reference's own per-column functions (ref_harness_soil.cc); returns lhs / rhs / hs as
+        soil_temperature_ex does."""
+        n = self.ncols
+        out = dict(lhs=np.zeros((n, 21, 5)), rhs=np.zeros((n, 21)), hs=np.zeros((n, 4)))
+        self._L.ref_soil.elmref_soil_temperature(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "hs")])
+        return out
 
     def set_init_params(self, organic_max, roota_par, rootb_par):
         """organic_max of the parameter file (initialize_elm_kokkos.cc:312) and PFTData::roota_par / rootb_par [25]."""

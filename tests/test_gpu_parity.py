@@ -113,8 +113,7 @@ def test_advance_chain_bit_identical():
 def test_snow_hydrology_next_row(tier, n, seed):
     """kokkos_snow_hydrology (snow_hydrology_kokkos.cc:23-188) on bit-identical inputs: the state after the seven wrappers and
     the temperature solve (so that imelt, swe_old, frac_iceold, qflx_snomelt ... are what the step produced).  Every field
-    bit-identical to the oracle's restatement, the new flag bits included (the oracle itself is parity-unpinned against the
-    reference for this row: oracle/elmo_physics_g.c)."""
+    bit-identical to the oracle's restatement, the new flag bits included (what pins the oracle for this row: oracle/elmo_physics_g.c)."""
     D, S = _pair(n, tier, seed)
     S.timestep7(DT)
     S.soil_temperature(DT)

@@ -1,9 +1,8 @@
 """Structural checks of the soil / snow temperature restatement (oracle/elmo_physics_d.c, CPU only).
 
-The reference has no fixture for this path, and the headers that hold the surface heat flux, the matrix factor and
-the RHS / LHS assembly (soil_temperature.h, soil_temp_rhs.h, soil_temp_lhs.h) do not compile without Kokkos, so those
-functions are PARITY UNPINNED against the reference (thermal properties, the solver and phase change are pinned bit
-for bit in tests/test_oracle_vs_ref.py).  What can be checked without the reference:
+The reference has no fixture for this path; the whole wrapper is pinned bit for bit by the reference's own per-column
+functions in tests/test_oracle_vs_ref.py (test_soil_temperature_whole_wrapper_bitwise).  These are the reference-free
+checks beside it:
   * the solver's output satisfies the assembled system;
   * the assembled system is consistent: with a uniform temperature profile and zero net surface heat flux the new
     temperatures equal the old ones (every row of the Crank-Nicolson matrix then reproduces T0 on its right-hand

@@ -41,7 +41,7 @@ for name, m in (("day", veg & day), ("night", veg & ~day)):
 ld = D.level_stride
 WK_DEBUG = 1
 nw = 4096
-w = D.read_work(WK_DEBUG * ld, nw * 16).reshape(nw, 16)
+w = D.read_work(WK_DEBUG * ld, nw * 32).reshape(nw, 32)
 w = w[w[:, 7] == 1.0]
 if len(w):
     t0 = w[:, 0].min()
@@ -53,15 +53,23 @@ if len(w):
     print(f"waves with work: {busy.sum()}, trips/wave mean {w[busy, 3].mean():.1f} max {w[busy, 3].max():.0f}; "
           f"lane utilisation over trips {w[busy, 4].sum() / (64 * w[busy, 3].sum()):.3f}; refills/wave {w[busy, 5].mean():.1f}; "
           f"us per trip {((end - start)[busy].sum() / w[busy, 3].sum()):.1f}")
-    # utilisation before / after the queue ran dry is not separable per trip here; report the tail length instead
     late = np.argsort(end)[-5:]
     print("latest waves: end us", np.round(end[late]), "trips", w[late, 3], "cols", w[late, 6], "refills", w[late, 5])
     print(f"tail: last wave ends {end.max() - np.nanmin(exh):.0f} us after the queue ran dry (kernel {end.max():.0f} us)")
     print(f"lane-trips {w[busy, 4].sum():.0f}: day {w[busy, 12].sum() / w[busy, 4].sum():.3f}; Brent used in {w[busy, 15].sum() / w[busy, 4].sum():.4f} of lane-trips, "
-          f"{w[busy, 14].sum() / w[busy, 3].sum():.3f} of wave-trips; wave-trips with a C4 lane {w[busy, 13].sum() / w[busy, 3].sum():.3f}")
-    sec = w[busy, 8:12].sum(axis=0)
+          f"{w[busy, 14].sum() / w[busy, 3].sum():.3f} of wave-trips; wave-trips with a C4 lane {w[busy, 13].sum() / w[busy, 3].sum():.3f}; "
+          f"wave-trips with a day lane {w[busy, 8].sum() / w[busy, 3].sum():.3f}")
+    # root-find statistics: ci_func evaluations per lane (what each column needs) against ci_func bodies the wave executed
+    for ph, name in ((0, "sunlit"), (1, "shaded")):
+        lane_ev, wave_ev = w[busy, 28 + ph].sum(), w[busy, 30 + ph].sum()
+        if wave_ev > 0:
+            print(f"ci_func {name}: {lane_ev:.0f} lane evaluations, {wave_ev:.0f} executed wave bodies -> active-lane fraction "
+                  f"{lane_ev / (64 * wave_ev):.3f}; bodies per day wave-trip {wave_ev / w[busy, 8].sum():.2f}; "
+                  f"evaluations per day lane-trip {lane_ev / w[busy, 12].sum():.2f}")
+    sec = w[busy, 16:28].sum(axis=0)
     if sec.sum() > 0:
-        names = ["refill+setup+friction", "resistances+psn_temp+psn sun", "psn shade+energy balance", "epilogue"]
+        names = ["refill+record load", "friction profiles", "resistances", "psn_temp + phase inputs", "solve sunlit", "solve shaded",
+                 "energy balance", "qsat + Monin-Obukhov + stop test", "store fin", "-", "-", "-"]
         print("shader-clock share per section:", {n: round(float(v / sec.sum()), 3) for n, v in zip(names, sec) if n != "-"},
               "cycles/trip", round(float(sec.sum() / w[busy, 3].sum())))
 else:

@@ -184,7 +184,7 @@ KERNEL_PREFIX = {
     "fused_stream": ("elmk::k_fz_",),
     "canopy_iterate": ("elmk::k_cf_iterate", "elmk::k_cf_finish"),
 }
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def kernel_source_hash():
@@ -218,6 +218,44 @@ def pmc_traffic(group, tier, cols, table=None):
     return float(sum(k[n]["hbm_bytes_per_launch"] for n in names))
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector fp64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (vendor figure)
+N_SIMD = 1024
+
+
+def compute_roofline(kernel_names, tier, cols, table=None):
+    """The compute side of the roofline for kernels that are not bandwidth-bound, from the committed SQ counter passes
+    (profiles/<round>_compute_pmc_tier{A,B}.json, tests/tools/make_compute_json.py; separate rocprofv3 --pmc passes).  Like
+    `traffic` it is only reported for the configuration and the build (source hash) it was measured on.
+      valu_busy       = SQ_ACTIVE_INST_VALU * 4 / (kernel cycles * 1024 SIMDs): share of the cycles a SIMD issues VALU work
+      valu_lane_util  = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): share of the 64 lanes doing it (divergence)
+      fp64_tflops     = (2 FMA + MUL + ADD + TRANS wave-instructions) * 64 lanes / kernel time: the issue rate of fp64
+                        arithmetic, all 64 lanes counted; x valu_lane_util = what the columns actually got"""
+    path = os.path.join(ROOT, "profiles", table or f"{PROFILE_TAG}_compute_pmc_tier{tier}.json")
+    if cols != 1_000_000 or not os.path.exists(path):
+        return None
+    doc = json.load(open(path))
+    if doc.get("source_hash") not in (None, kernel_source_hash()):
+        print(f"bench.py: {os.path.basename(path)} was measured on another build of the kernels: compute_roofline = null", file=sys.stderr)
+        return None
+    out = {}
+    for name in kernel_names:
+        k = doc["kernels"].get(name)
+        if not k:
+            continue
+        cyc = k["GRBM_GUI_ACTIVE"] / 8.0
+        secs = cyc / 2.4e9
+        busy = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * N_SIMD)
+        lane = k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
+        flops = (2 * k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"]) * 64.0
+        tf = flops / secs / 1e12
+        out[name] = {"valu_busy": round(busy, 3), "valu_lane_util": round(lane, 3), "fp64_tflops": round(tf, 2),
+                     "frac_of_fp64_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 3), "fp64_tflops_active_lanes": round(tf * lane, 2),
+                     "valu_insts_per_launch": k["SQ_INSTS_VALU"], "fp64_share_of_valu_insts": round(
+                         (k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
+                         / k["SQ_INSTS_VALU"], 3), "avg_launch_ms_counter_pass": round(secs * 1e3, 4)}
+    return out or None
+
+
 SOIL_ALGO_BYTES = 2860  # soil_temperature: 1972 B read + 888 B written per column (tally in DESIGN.md section 9)
 SOIL_RESTORE = ["t_soisno", "h2osoi_ice", "h2osoi_liq", "t_h2osfc", "h2osfc", "h2osno", "snow_depth", "int_snow", "t_grnd"]
 
@@ -240,6 +278,9 @@ def make_step(D, workload, fused=False):
     return step
 
 
+PER_RANK_SECONDS = []  # of the last timed_steps call with a process group (rank order)
+
+
 def timed_steps(D, workload, steps, warmup, sync_all, dist, torch, red_device="cuda", fused=False):
     """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks -> seconds."""
     step = make_step(D, workload, fused)
@@ -255,10 +296,16 @@ def timed_steps(D, workload, steps, warmup, sync_all, dist, torch, red_device="c
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if dist is not None:
+        # every rank's own seconds (a straggler GPU shows here), then the maximum - the time the job took
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+        allt = [torch.zeros(1, dtype=torch.float64, device=red_device) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    PER_RANK_SECONDS[:] = per_rank
     return elapsed
 
 
@@ -280,24 +327,76 @@ def active_bytes(veg_frac, sun_frac):
     return act
 
 
-def spawn_ranks(ngpus, argv):
-    """`python bench.py --gpus N` with no launcher: start N rank processes (one per GPU), relay rank 0's JSON line.
-    The parent initialises nothing on the GPU (torch is not even imported here) and never re-executes itself."""
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(ngpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+        return s.getsockname()[1]
+
+
+def _stop(procs):
+    """Terminate the rank processes that are still running (plain signals to our own children; nothing is re-executed)."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    t_end = time.time() + 5.0
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def spawn_ranks(ngpus, argv, timeout_s=None, poll_s=0.2):
+    """`python bench.py --gpus N` with no launcher: start N rank processes (one per GPU), relay rank 0's JSON line.
+    The parent initialises nothing on the GPU (torch is not even imported here) and never re-executes itself.  It polls its
+    children: the first one that exits non-zero (or an overall timeout, ELMK_BENCH_TIMEOUT seconds, default 3000) ends the
+    others within seconds and becomes the exit code - a rank that dies before the barrier must not leave the rest waiting
+    in the rendezvous for the backend's timeout.  The rendezvous port is picked by bind-and-close; if another process takes
+    it before rank 0 listens, the ranks fail at once with EADDRINUSE and the spawn is retried on a fresh port."""
+    import tempfile
+
+    timeout_s = float(os.environ.get("ELMK_BENCH_TIMEOUT", "3000")) if timeout_s is None else timeout_s
+    for attempt in range(3):
+        port = _free_port()
+        out0 = tempfile.TemporaryFile()
+        err0 = tempfile.TemporaryFile()
+        procs = []
+        for r in range(ngpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err0 if r == 0 else None))
+        t0 = time.time()
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = abs(bad[0][1]) or 1
+                print(f"bench.py: rank {bad[0][0]} exited with {bad[0][1]}: stopping the other ranks", file=sys.stderr)
+                _stop(procs)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > timeout_s:
+                print(f"bench.py: ranks still running after {timeout_s:.0f} s: stopping them", file=sys.stderr)
+                _stop(procs)
+                rc = 124
+                break
+            time.sleep(poll_s)
+        err0.seek(0)
+        err_text = err0.read().decode(errors="replace")
+        if rc and attempt < 2 and time.time() - t0 < 60 and ("EADDRINUSE" in err_text or "address already in use" in err_text.lower()):
+            print("bench.py: rendezvous port was taken: retrying on another port", file=sys.stderr)
+            continue
+        sys.stderr.write(err_text)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+        return rc
+    return 1
 
 
 def main(argv=None):
@@ -323,6 +422,9 @@ def main(argv=None):
                     help="replay the seven wrappers as one captured HIP graph (elmk_set_graph): removes host launch latency, "
                          "which dominates below ~100k columns")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the per-kernel HIP-event profile")
+    ap.add_argument("--one-gpu-value", type=float, default=None,
+                    help="the 1-GPU `value` of the same configuration: with it the line carries scaling_efficiency = value / (N * that)")
+    ap.add_argument("--no-soil-10m", action="store_true", help="skip the soil-column solve at 10 M columns (soil_temperature_10M)")
     args = ap.parse_args(argv)
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -427,6 +529,21 @@ def main(argv=None):
     elapsed, ms, ms_total = measure(D, args.steps, args.warmup, True)
     flags, first_bad = D.error_summary()
     state_gb = round(D.device_bytes / 1e9, 3)
+    step_time = None
+    empirical = None
+    if rehearsal is None and rank == 0:
+        if not soil:
+            # device time of every step (HIP events around each, same restores): SURVEY 8(d) asks for the median
+            each = sorted(D.profile_steps(1800.0, max(3, args.steps), fused=args.fused))
+            step_time = {"n": len(each), "median_ms": each[len(each) // 2] if len(each) % 2 else 0.5 * (each[len(each) // 2 - 1] + each[len(each) // 2]),
+                         "mean_ms": sum(each) / len(each), "min_ms": each[0], "max_ms": each[-1], "how": "HIP events around each step"}
+        if world == 1:
+            # the empirical HBM line of this box beside the datasheet peak: a device-to-device copy of 1 GiB in four access
+            # shapes (the best is the line), and the same bytes as 64 + 64 separate streams (what a many-field kernel sees)
+            shapes = {sh: D.copy_bandwidth(1 << 30, 10, sh) for sh in range(5)}
+            empirical = {"copy_GBps_by_shape": {"8B_per_lane": round(shapes[0], 1), "16B_per_lane": round(shapes[1], 1),
+                                                "8B_per_lane_x4_loads": round(shapes[2], 1), "16B_per_lane_x4_loads": round(shapes[3], 1)},
+                         "peak_GBps": round(max(shapes[k] for k in range(4)), 1), "many_stream_GBps": round(shapes[4], 1)}
     names = [] if rehearsal is not None else (st.KERNEL_NAMES_FUSED if args.fused else st.KERNEL_NAMES)
     also_fused = rank == 0 and world == 1 and rehearsal is None and not args.fused and not (args.workload == "soil_temperature")
     fused_step = None
@@ -480,6 +597,26 @@ def main(argv=None):
                 north[TIER_NAMES[tier]]["fused_step"] = fused_too(Dn, NORTH_STAR_COLS, 5, 2)
             Dn.close()
 
+    soil10 = None
+    if solo and not soil and not args.no_soil_10m and not args.no_north_star and args.cols < NORTH_STAR_COLS:
+        # BASELINE config 3 in the same run: the soil-column vertical solve at 10 M columns (branch-mix tier: resolved snow
+        # layers, ponded water, frozen soil), state left by the seven wrappers, 5 solves timed by HIP events
+        if D is not None:
+            D.close()
+            D = None
+        Ds, _ = build_state(NORTH_STAR_COLS, device_index, "B", args.seed)
+        st.timestep7(Ds, 1800.0)
+        Ds.snapshot_fields(SOIL_RESTORE)
+        Ds.sync()
+        event_time_soil(Ds, 2)
+        ms10 = event_time_soil(Ds, 5)
+        gbs10 = SOIL_ALGO_BYTES * NORTH_STAR_COLS / (ms10 * 1e-3) / 1e9
+        soil10 = {"workload": "soil-column vertical solve (kokkos_soil_temperature), 10 M columns, branch-mix tier, fp64", "columns": NORTH_STAR_COLS,
+                  "value": NORTH_STAR_COLS / (ms10 * 1e-3), "unit": "columns/s", "ms_per_solve_events": ms10,
+                  "roofline": {"bound": "hbm", "kernel": "k_soil_temperature", "achieved": gbs10, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs10 / HBM_PEAK_GBS, "bytes_per_column": SOIL_ALGO_BYTES}}
+        Ds.close()
+
     if rank == 0:
         value = ncols_global * args.steps / elapsed
         tier_name = TIER_NAMES[args.tier]
@@ -497,6 +634,13 @@ def main(argv=None):
             "dtype": "f64",
             "data": "synthetic",
         }
+        if world > 1:
+            # every rank's own time for the K steps (ms per step): a straggler GPU is visible here, the job's time is the maximum
+            out["per_rank_ms"] = [round(t / args.steps * 1e3, 4) for t in PER_RANK_SECONDS]
+            if args.one_gpu_value:
+                out["scaling_efficiency"] = value / (world * args.one_gpu_value)
+        if step_time is not None:
+            out["step_time"] = step_time
         par = f"columns block-split over {world} rank(s) on {min(world, max(ndev, 1))} GPU(s), no collective"
         if rehearsal is not None:
             out["config"] = {"workload": "CPU rehearsal of the multi-rank control flow (tests only)", "columns_per_gpu": args.cols,
@@ -511,6 +655,10 @@ def main(argv=None):
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "traffic": pmc_traffic("soil_temperature", args.tier, args.cols, f"{PROFILE_TAG}_hbm_traffic_pmc_soil_tier{args.tier}.json"),
                                "bytes_per_column": SOIL_ALGO_BYTES, "avg_launch_ms": ms_total}
+            if empirical is not None:
+                out["roofline"]["empirical_peak"] = empirical["peak_GBps"]
+                out["roofline"]["frac_of_empirical_peak"] = gbs / empirical["peak_GBps"]
+                out["roofline"]["empirical"] = empirical
         else:
             act = active_bytes(veg_frac, sun_frac)
             kern = {}
@@ -538,13 +686,28 @@ def main(argv=None):
                 "workload": f"full water+energy timestep (7 kernels{', fused streaming stage' if args.fused else ''}), {args.cols} columns x 20 soil+snow levels per GPU, fp64",
                 "columns_per_gpu": args.cols, "columns_total": ncols_global, "levels": 20, "tier": tier_name, "parallelism": par,
             }
+            # which roof applies, from evidence: the committed SQ counter table of this build says how busy the vector ALUs
+            # are in the kernels that are not streaming kernels (canopy_fluxes' leaf-temperature iteration, SNICAR)
+            comp = compute_roofline(["k_cf_iterate", "k_alb_snicar<1>", "k_bg_flux", "k_cf_init", "k_alb_final"], args.tier, args.cols)
+            dom_compute = {"canopy_fluxes": "k_cf_iterate", "canopy_iterate": "k_cf_iterate", "albedo_snicar": "k_alb_snicar<1>"}.get(dom[0])
+            bound = "hbm"
+            if comp and dom_compute in comp and comp[dom_compute]["valu_busy"] > 0.70:
+                bound = "fp64_valu"
             out["roofline"] = {
-                "bound": "hbm", "kernel": f"{dom[0]} ({', '.join(p.replace('elmk::', '') + '*' for p in KERNEL_PREFIX.get(dom[0], ()))})",
+                "bound": bound, "kernel": f"{dom[0]} ({', '.join(p.replace('elmk::', '') + '*' for p in KERNEL_PREFIX.get(dom[0], ()))})",
                 "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom[0], args.tier, args.cols,
                                        f"{PROFILE_TAG}_hbm_traffic_pmc_fused_tier{args.tier}.json" if args.fused else None),
                 "bytes_per_column": dom_bytes, "avg_launch_ms": dom[1],
+                "bound_evidence": (f"{dom_compute}: VALU busy {comp[dom_compute]['valu_busy']:.2f} of the cycles (committed SQ counter pass of this build)"
+                                   if comp and dom_compute in comp else "no counter table for this build: bound not established"),
             }
+            if empirical is not None:
+                out["roofline"]["empirical_peak"] = empirical["peak_GBps"]
+                out["roofline"]["frac_of_empirical_peak"] = dom_gbs / empirical["peak_GBps"]
+                out["roofline"]["empirical"] = empirical
+            if comp:
+                out["compute_roofline"] = {"peak_fp64_vector_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "kernels": comp}
             out["timestep_roofline"] = {
                 "bytes_per_column_step": step_bytes, "achieved_GBps": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                 "ms_per_step_events": ms_total,
@@ -564,6 +727,8 @@ def main(argv=None):
             out["advance_step"] = advance_step
         if north is not None:
             out["north_star_10M"] = north
+        if soil10 is not None:
+            out["soil_temperature_10M"] = soil10
         if not args.no_cpu_baseline and world == 1 and rehearsal is None:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(host_state, workload=args.workload)
         print(json.dumps(out), flush=True)

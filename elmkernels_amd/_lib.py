@@ -67,6 +67,7 @@ SIGNATURES = {
     "elmk_profile_timestep7": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_profile_wrapper": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "elmk_read_scratch": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64]),
+    "elmk_profile_steps": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "elmk_copy_bandwidth": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "elmk_copy_bandwidth_shape": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "elmk_math_eval": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64]),

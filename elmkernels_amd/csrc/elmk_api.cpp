@@ -216,7 +216,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
   const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
   const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
-  const size_t cnt_bytes = align_up((size_t)(2 * NLISTS + CF_NCLS) * CPAD * 4, 256);
+  const size_t cnt_bytes = align_up((size_t)(2 * NLISTS + CF_NCLS + 2) * CPAD * 4, 256);  // (+ the canopy queue's tail and grant counters)
   const size_t hint_bytes = align_up((size_t)ctx->ld * 4, 256);
   // canopy_fluxes queue records (k_canopy_fluxes.hip), by queue position
   const int64_t cf_nblk = (ncols + 255) / 256 > 0 ? (ncols + 255) / 256 : 1;
@@ -858,7 +858,8 @@ int run_graph(elmk_ctx* ctx, GraphSlot& g, stage_fn fn, int nstage, double dt)
 
 // nsteps profiled steps: HIP events between the stages on the context's stream; the snapshot (if any) is restored before
 // every step outside the event brackets, so each profiled step does the same work as the caller's timed loop
-int profile_stages(elmk_ctx* ctx, stage_fn fn, int nstage, double dt, int nsteps, float* ms_per_stage, float* ms_total)
+int profile_stages(elmk_ctx* ctx, stage_fn fn, int nstage, double dt, int nsteps, float* ms_per_stage, float* ms_total,
+                   float* ms_each_step = nullptr)
 {
   EventList ev;
   HIPCHK(ev.create((size_t)nsteps * (nstage + 1)));
@@ -880,6 +881,7 @@ int profile_stages(elmk_ctx* ctx, stage_fn fn, int nstage, double dt, int nsteps
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e[0], e[nstage]));
     tot += ms;
+    if (ms_each_step) ms_each_step[s] = ms;
   }
   if (ms_per_stage)
     for (int k = 0; k < nstage; k++) ms_per_stage[k] = (float)(acc[k] / nsteps);
@@ -966,6 +968,14 @@ int elmk_profile_timestep7_fused(elmk_ctx* ctx, double dt, int nsteps, float* ms
   return profile_stages(ctx, launch_stage_fused, ELMK_FUSED_NSTAGE, dt, nsteps, ms_per_stage, ms_total);
 }
 
+int elmk_profile_steps(elmk_ctx* ctx, int fused, double dt, int nsteps, float* ms_each_step)
+{
+  PHYSICS_PROLOGUE();
+  if (nsteps <= 0 || !ms_each_step) return invalid(ctx, "elmk_profile_steps: bad arguments");
+  return fused ? profile_stages(ctx, launch_stage_fused, ELMK_FUSED_NSTAGE, dt, nsteps, nullptr, nullptr, ms_each_step)
+               : profile_stages(ctx, launch_stage7, TS7_NSTAGE, dt, nsteps, nullptr, nullptr, ms_each_step);
+}
+
 namespace {
 void launch_one_wrapper(elmk_ctx* ctx, int wrapper, double dt)
 {
@@ -1044,8 +1054,8 @@ int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_
 int elmk_copy_bandwidth_shape(elmk_ctx* ctx, int64_t bytes, int iters, int shape, double* gbytes_per_s)
 {
   if (int rc = enter(ctx)) return rc;
-  if (bytes < 64 || iters <= 0 || shape < 0 || shape > 3 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
-  const int64_t n = (bytes / 64) * 8;  // whole 64-byte runs: every shape copies the same bytes
+  if (bytes < 512 || iters <= 0 || shape < 0 || shape > 4 || !gbytes_per_s) return invalid(ctx, "elmk_copy_bandwidth: bad arguments");
+  const int64_t n = (bytes / 512) * 64;  // whole 512-byte runs: every shape copies the same bytes
   DevBuf a, b;
   if (hip_fail(ctx, a.alloc((size_t)n * 8), "hipMalloc") || hip_fail(ctx, b.alloc((size_t)n * 8), "hipMalloc")) return ELMK_E_NOMEM;
   EventList ev;

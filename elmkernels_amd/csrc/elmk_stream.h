@@ -62,10 +62,64 @@ __device__ __forceinline__ void frac_wet_col(const DevState* __restrict__ S, con
 // =====================================================================================================
 // interception :8, ground_flux :83, snow_init :146, fraction_h2osfc :312 of canopy_hydrology_impl.hh
 // =====================================================================================================
-template <bool FUSED>
-__device__ __forceinline__ void canopy_hydrology_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                                     const double dtime, ColFwd& w)
+// fraction_h2osfc's Newton solve (:325-333: ten fixed iterations, three erf and one exp each) only runs where water is ponded
+// - a few columns in a hundred - so as part of the per-column body it kept a whole wave busy for the few lanes that needed it
+// (VALU lane utilisation of k_canopy_hydrology on the branch-mix tier: 15 %, profiles/r03_lane_utilisation_before.txt).
+// The body is therefore cut in two around it and the solves of a workgroup are done together: every thread hands its
+// (sigma, h2osfc) to a list in LDS, the first threads of the workgroup solve one entry each with all their lanes busy, and
+// every column takes its frac_h2osfc back.  Which lane evaluates the ten iterations changes nothing about their result.
+struct HydroMid {
+  bool live;  // false: the wrapper does nothing more on this column (lake land units)
+  int snl;
+  double frac_sno, frac_sno_eff, h2osno, snow_depth, int_snow, h2osfc;
+};
+__device__ __forceinline__ double pond_fraction(const double sigma, const double h2osfc)
 {
+  double d = 0.0;
+#pragma unroll 1
+  for (int l = 0; l < 10; l++) {
+    const double fd = 0.5 * d * (1.0 + elmk_erf(d / (sigma * sqrt(2.0)))) +
+                      sigma / sqrt(2.0 * ELM_PI) * elmk_exp(-elmk_sq(d) / (2.0 * elmk_sq(sigma))) - h2osfc;
+    const double dfdd = 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
+    d = d - fd / dfdd;
+  }
+  return 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
+}
+// All threads of the (256-thread) workgroup call this; returns the thread's own frac_h2osfc if it asked for one.
+__device__ __forceinline__ double block_pond_fraction(const bool need, const double sigma, const double h2osfc)
+{
+  __shared__ double s_sigma[256], s_h2osfc[256], s_frac[256];
+  __shared__ uint32_t s_owner[256];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+  const unsigned long long m = __ballot(need);
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (need) {
+      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      s_sigma[slot] = sigma;
+      s_h2osfc[slot] = h2osfc;
+      s_owner[slot] = threadIdx.x;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < s_n) s_frac[s_owner[threadIdx.x]] = pond_fraction(s_sigma[threadIdx.x], s_h2osfc[threadIdx.x]);
+  __syncthreads();
+  return need ? s_frac[threadIdx.x] : 0.0;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void canopy_hydrology_head(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                                      const double dtime, ColFwd& w, HydroMid& mid, bool& pond, double& pond_sigma)
+{
+  mid.live = false;
+  pond = false;
+  pond_sigma = 0.0;
   const int fvn = S->frac_veg_nosno[c];
   int snl = S->snl[c];
   const double forc_t = S->forc_tbot[c];
@@ -269,21 +323,36 @@ __device__ __forceinline__ void canopy_hydrology_col(const DevState* __restrict_
     LV(dz, k) = LV(dz, k) + dz_snowf;
   }
 
-  // ---- fraction_h2osfc (:312-357)
-  double h2osfc = S->h2osfc[c];
+  // ---- fraction_h2osfc (:312-357): the solve itself happens between head and tail (block_pond_fraction)
+  const double h2osfc = S->h2osfc[c];
+  if ((L.ltype == istsoil || L.ltype == istcrop) && h2osfc > 1.e-8) {
+    pond = true;
+    pond_sigma = 1.0e3 * S->micro_sigma[c];
+  }
+  mid.live = true;
+  mid.snl = snl;
+  mid.frac_sno = frac_sno;
+  mid.frac_sno_eff = frac_sno_eff;
+  mid.h2osno = h2osno;
+  mid.snow_depth = snow_depth;
+  mid.int_snow = int_snow;
+  mid.h2osfc = h2osfc;
+}
+
+// pond_frac: block_pond_fraction's answer for this column (read only where canopy_hydrology_head asked for it)
+template <bool FUSED>
+__device__ __forceinline__ void canopy_hydrology_tail(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                                      ColFwd& w, const HydroMid& mid, const double pond_frac)
+{
+  if (!mid.live) return;
+  const int snl = mid.snl;
+  double frac_sno = mid.frac_sno, frac_sno_eff = mid.frac_sno_eff;
+  const double h2osno = mid.h2osno, snow_depth = mid.snow_depth, int_snow = mid.int_snow;
+  double h2osfc = mid.h2osfc;
   double frac_h2osfc;
   if (L.ltype == istsoil || L.ltype == istcrop) {
     if (h2osfc > 1.e-8) {
-      double d = 0.0;
-      const double sigma = 1.0e3 * S->micro_sigma[c];
-#pragma unroll 1
-      for (int l = 0; l < 10; l++) {
-        const double fd = 0.5 * d * (1.0 + elmk_erf(d / (sigma * sqrt(2.0)))) +
-                          sigma / sqrt(2.0 * ELM_PI) * elmk_exp(-elmk_sq(d) / (2.0 * elmk_sq(sigma))) - h2osfc;
-        const double dfdd = 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
-        d = d - fd / dfdd;
-      }
-      frac_h2osfc = 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
+      frac_h2osfc = pond_frac;
     } else {
       frac_h2osfc = 0.0;
       LV(h2osoi_liq, NLEVSNO) = LV(h2osoi_liq, NLEVSNO) + h2osfc;
@@ -313,6 +382,20 @@ __device__ __forceinline__ void canopy_hydrology_col(const DevState* __restrict_
   w.frac_sno_eff = frac_sno_eff;
   w.frac_h2osfc = frac_h2osfc;
   w.snow_depth = snow_depth;
+}
+
+// the whole wrapper for one column; EVERY thread of the workgroup calls it (inside: the thread has a column)
+template <bool FUSED>
+__device__ __forceinline__ void canopy_hydrology_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                                     const double dtime, ColFwd& w, const bool inside)
+{
+  HydroMid mid;
+  mid.live = false;
+  bool pond = false;
+  double sigma = 0.0;
+  if (inside) canopy_hydrology_head<FUSED>(S, c, ld, L, dtime, w, mid, pond, sigma);
+  const double pond_frac = block_pond_fraction(pond, sigma, mid.live ? mid.h2osfc : 0.0);
+  if (inside) canopy_hydrology_tail<FUSED>(S, c, ld, L, w, mid, pond_frac);
 }
 
 // =====================================================================================================

@@ -301,6 +301,9 @@ __device__ __forceinline__ PsnTemp psn_temp(const double* R, bool c3flag, double
   PsnTemp T;
   T.ft_lmr = T.fth_lmr = T.e_lmr_c4 = T.e_vc4a = T.e_vc4b = T.p2 = 0.0;
   T.ft_vcmax = T.fth_vcmax = T.ft_jmax = T.fth_jmax = T.ft_tpu = T.fth_tpu = T.kc = T.ko = T.cp = 0.0;
+  // Night columns (par_z <= 0 in both phases, or no canopy layer) need none of this: their stomatal resistance is
+  // min(rsmax0, 1 / bbb * cf) (:161-173) and the respiration rate lmr_z only enters an, which the wrapper does not keep.
+  if (!day) return T;
   const double fac = (1.0 - (TFRZ + 25.0) / t_veg);
   if (c3flag) {
     T.ft_lmr = psn_ft_c(R[PFT_lmrha_c], fac);
@@ -309,7 +312,7 @@ __device__ __forceinline__ PsnTemp psn_temp(const double* R, bool c3flag, double
     T.p2 = elmk_pow(2.0, ((t_veg - (TFRZ + 25.0)) / 10.0));
     T.e_lmr_c4 = elmk_exp(1.3 * (t_veg - (TFRZ + 55.0)));
   }
-  if (day) {
+  {
     if (c3flag) {  // (kp_z = kp25 * 2^((t-25)/10) is only ever read by the C4 branch of ci_func)
       T.ft_vcmax = psn_ft_c(R[PFT_vcmaxha_c], fac);
       T.fth_vcmax = psn_fth(t_veg, R[PFT_vcmaxhd], vcmaxse, vcmaxc);
@@ -478,6 +481,15 @@ constexpr int CF_REFILL_MIN = 8;
 #define CF_PRIO_TRIPS 10  // trips after which a column makes its wave a priority wave (k_cf_iterate)
 #endif
 constexpr int CF_BLOCK_EXTRA = 24;  // queue positions a wave claims beyond what a refill needs (its private block)
+// Measured and dropped in round 3 (profiles/r03_cf_probe_two_*_queue_tier*.txt): separating day from night waves.  With one
+// head, day before night, every wave crosses from day to night columns mid-kernel and runs a dozen trips at the price of a day
+// trip for the few day lanes it still has (24 % of the lanes of all day-priced wave-trips are night or idle lanes).  Two
+// variants kept the kinds apart - a two-ended queue (day from the front, night from the back) and two parts with a head each,
+// waves split by estimated work - and both did what they were built for (day-priced wave-trips 56 % -> 44-47 % of all
+// wave-trips, active lanes in the root finds 73 % -> 90 %), but they postpone the short day classes to the end of the kernel,
+// and that is where the few columns sit that jump from a handful of trips to the 41-trip limit from one call to the next: each
+// of them then runs 41 trips past the end of the queue.  Tier A gained 1.4 % of the step, tier B lost 2-3 %.
+// Day-first keeps every day column in the first 60 % of the kernel, which bounds that tail.
 
 // doubles of a queue record (k_cf_init -> k_cf_iterate): the column's inputs of the iteration that are not recomputed
 // from other record fields at a few instructions each when the column is loaded (w_lai, cf, cp25, the t10 terms, qsat of
@@ -1604,8 +1616,8 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
     ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
   }
   ColFwd w;
+  canopy_hydrology_col<true>(S, c, ld, L, dtime, w, inside);  // (every thread: the pond solves are pooled per workgroup)
   if (inside) {
-    canopy_hydrology_col<true>(S, c, ld, L, dtime, w);
     surface_radiation_col<true>(S, c, ld, L, w);
     canopy_temperature_col<true>(S, c, ld, L, w);
   }

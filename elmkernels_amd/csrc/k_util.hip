@@ -219,10 +219,25 @@ __global__ __launch_bounds__(256) void k_copy_x4(const T* __restrict__ src, T* _
   }
 }
 
+//   shape 4:  8 bytes per lane, 64 separate streams read and 64 written by every thread (the n doubles seen as 64 fields of
+//            n / 64 columns, field-major like the state): the line a many-field streaming kernel can reach - HBM sustains fewer
+//            bytes per second over a hundred open streams than over two (profiles/r03_stream_layout_ubench.txt)
+__global__ __launch_bounds__(256) void k_copy_streams(const double* __restrict__ src, double* __restrict__ dst, int64_t ncol)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  double v[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++) v[k] = src[(int64_t)k * ncol + c];
+#pragma unroll
+  for (int k = 0; k < 64; k++) dst[(int64_t)k * ncol + c] = v[k];
+}
+
 void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st, int shape)
 {
   if (n <= 0) return;
   switch (shape) {
+    case 4: hipLaunchKernelGGL(k_copy_streams, dim3((unsigned)((n / 64 + 255) / 256)), dim3(256), 0, st, src, dst, n / 64); break;
     case 1: hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, (const double2*)src, (double2*)dst, n / 2); break;
     case 2: hipLaunchKernelGGL(k_copy_x4<double>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, dst, n); break;
     case 3: hipLaunchKernelGGL(k_copy_x4<double2>, dim3((unsigned)((n / 2 + 1023) / 1024)), dim3(256), 0, st, (const double2*)src, (double2*)dst, n / 2); break;

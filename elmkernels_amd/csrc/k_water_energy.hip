@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void k_frac_wet(const DevState* __restrict__ S
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_canopy_hydrology(const DevState* __restrict__ S, double dtime)
 {
-  COL_GUARD();
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
   ColFwd w;
-  canopy_hydrology_col<false>(S, c, ld, S->land, dtime, w);
+  canopy_hydrology_col<false>(S, c, ld, S->land, dtime, w, c < S->ncols);  // (every thread: the pond solves are pooled per workgroup)
 }
 
 __global__ __launch_bounds__(256) void k_surface_radiation(const DevState* __restrict__ S)

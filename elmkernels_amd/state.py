@@ -220,6 +220,12 @@ class ELMState:
         self._chk(self.lib.elmk_profile_timestep7_fused(self.ctx, float(dt), int(nsteps), ms, C.byref(tot)), "profile_timestep7_fused")
         return list(ms), tot.value
 
+    def profile_steps(self, dt, nsteps, fused=False):
+        """Device time (ms) of each of nsteps steps (HIP events around every step; snapshot restored before each)."""
+        ms = (C.c_float * int(nsteps))()
+        self._chk(self.lib.elmk_profile_steps(self.ctx, int(bool(fused)), float(dt), int(nsteps), ms), "profile_steps")
+        return list(ms)
+
     def canopy_trip_counts(self):
         """Trips of the leaf-temperature iteration per column in the last canopy_fluxes call (0: not vegetated)."""
         out = np.zeros(self.ncols, dtype=np.int32)

@@ -306,6 +306,10 @@ typedef enum {
   ELMK_WRAPPER_ADVANCE_PHYSICS /* elmk_advance_physics: all ten in the reference's order */
 } elmk_wrapper;
 int elmk_profile_wrapper(elmk_ctx *ctx, int wrapper, double dt, int nsteps, float *ms_mean);
+/* device time of each of nsteps steps of elmk_timestep7 (fused = 0) or elmk_timestep7_fused (fused != 0), by HIP events
+ * around every step on the context's stream, the snapshot restored before every step outside the brackets: what the
+ * benchmark takes its median step time from */
+int elmk_profile_steps(elmk_ctx *ctx, int fused, double dt, int nsteps, float *ms_each_step);
 /* Read back context-owned scratch (diagnostics; not part of the state contract).
  *   ELMK_SCRATCH_CF_TRIPS: int32 per column - trips of the leaf-temperature iteration
  *                          (canopy_fluxes_impl.hh:233-450) in the last elmk_canopy_fluxes call, 0 = not vegetated
@@ -318,7 +322,9 @@ int elmk_read_scratch(elmk_ctx *ctx, int kind, void *host, int64_t offset, int64
 int elmk_copy_bandwidth(elmk_ctx *ctx, int64_t bytes, int iters, double *gbytes_per_s);
 /* the same probe in a chosen access shape: 0 = 8 bytes per lane, one load per thread (the shape of elmk_copy_bandwidth and of
  * the snapshot restore); 1 = 16 bytes per lane; 2 = 8 bytes per lane, four independent loads per thread; 3 = 16 bytes per
- * lane, four independent loads per thread.  bench.py reports the best of them as roofline.empirical_peak. */
+ * lane, four independent loads per thread; 4 = 8 bytes per lane, 64 separate streams read and 64 written by every thread
+ * (the buffer seen as 64 fields, field-major like the state).  bench.py reports the best of 0..3 as roofline.empirical_peak
+ * and shape 4 as the line of a many-field streaming kernel. */
 int elmk_copy_bandwidth_shape(elmk_ctx *ctx, int64_t bytes, int iters, int shape, double *gbytes_per_s);
 /* Evaluate one function of elmkernels_amd/csrc/elmk_math.h - the device restatement of the host libm's exp / log / log10 /
  * pow / atan / tanh / cos / erf / acos / expm1 (the <cmath> calls of src/physics headers) - on n host values: out[i] = fn(x[i]) or pow(x[i], y[i]).

@@ -32,6 +32,9 @@ class RehearsalState:
         self.base = self.S.clone()
 
     def rehearsal_step(self):
+        # test hook: one rank dies before the barrier (tests/test_sharding_gloo.py checks that the launcher ends the others)
+        if os.environ.get("ELMK_REHEARSAL_DIE_RANK") == str(self.rank):
+            os._exit(7)
         self.S.copy_from(self.base)  # every step starts from the same state: the result is that of ONE timestep
         self.S.timestep7(1800.0)
         self.steps += 1

@@ -108,6 +108,29 @@ def test_bench_main_spawns_its_own_ranks(tmp_path):
     line = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--cols", "700", "--steps", "2", "--warmup", "1",
                        "--tier", "B", "--no-cpu-baseline"], tmp_path, 1400)
     _check_shards(tmp_path, line, 700, 2, 2, 1)
+    # every rank's own time is in the line (a straggler would show), the job's time is their maximum
+    assert len(line["per_rank_ms"]) == 2 and abs(max(line["per_rank_ms"]) - line["ms_per_step"]) < 1e-3 * line["ms_per_step"] + 1e-3
+
+
+def test_a_rank_that_dies_early_ends_the_run_within_seconds(tmp_path):
+    """One rank exits before the barrier: the parent must stop the other rank (which is waiting in the rendezvous or in the
+    barrier) and return non-zero quickly, not after the backend's timeout."""
+    import subprocess
+    import time
+
+    env = dict(os.environ, ELMK_BENCH_REHEARSAL="tests.rehearsal:make_state", ELMK_REHEARSAL_OUT=str(tmp_path),
+               ELMK_REHEARSAL_NGLOBAL="400", ELMK_REHEARSAL_DIE_RANK="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--cols", "200", "--steps", "2", "--warmup", "1", "--tier", "B",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    took = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-1500:])
+    assert "rank 1 exited with 7" in r.stderr.decode()
+    assert took < 120, took  # (importing torch twice takes most of it; the gloo timeout would be 30 minutes)
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]  # no result line from a broken run
 
 
 def test_bench_main_under_torch_distributed_run(tmp_path):

@@ -4,7 +4,7 @@
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 T=${1:-prof}
-P=${PROFILE_TAG:-r02}
+P=${PROFILE_TAG:-r03}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +17,14 @@ for spec in "A timestep7 tierA" "B timestep7 tierB" "A fused fused_tierA" "B fus
   python3 $R/tests/tools/make_traffic_json.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic_pmc_$name.json 1000000 $tier | tee $O/hbm_traffic_$name.txt
   cp $O/hbm_traffic_pmc_$name.json $R/profiles/${P}_hbm_traffic_pmc_$name.json
   rm -rf $O/pmc_fetch $O/pmc_write
+done
+# 1b. the compute side (SQ counters, one group per pass): VALU busy, VALU lane utilisation, fp64 instruction mix of every kernel
+for tier in A B; do
+  rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_lane -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 1000000 $tier timestep7 > $O/pmc_lane_$tier.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 -d $O/pmc_f64 -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 1000000 $tier timestep7 > $O/pmc_f64_$tier.log 2>&1
+  python3 $R/tests/tools/make_compute_json.py $O/compute_pmc_tier$tier.json 1000000 $tier $O/pmc_lane $O/pmc_f64 | tee $O/compute_pmc_tier$tier.txt
+  cp $O/compute_pmc_tier$tier.json $R/profiles/${P}_compute_pmc_tier$tier.json
+  rm -rf $O/pmc_lane $O/pmc_f64
 done
 # 2. the benchmark line (reads the tables written above) and its rocprofv3 kernel statistics
 cd $R

@@ -59,14 +59,14 @@ TIER_NAMES = {"A": "fixture-tiled", "B": "branch-mix"}
 REHEARSAL_ENV = "ELMK_BENCH_REHEARSAL"
 
 
-def build_state(ncols, device, tier, seed):
+def build_state(ncols, device, tier, seed, lib_path=None):
     from elmkernels_amd import state as st
     from elmkernels_amd import synth
 
     ft = st.field_table()
     nbase = min(NBASE, ncols)
     cols, scal, soil = synth.make_state(ft, nbase, tier=tier, seed=seed)
-    D = st.ELMState(ncols, device)
+    D = st.ELMState(ncols, device, lib_path=lib_path)
     pft, optics = synth.load_params()
     D.set_pft(pft)
     D.set_snicar(optics)
@@ -347,6 +347,90 @@ def _stop(procs):
             p.wait()
 
 
+ALGO_BYTES_FUSED_F32 = 1721  # the fused bound with an fp32 state: 3 368 B of fp64 fields halved + 37 B of int / bool fields
+
+
+def fp32_state_variant(device_index, seed, st):
+    """BASELINE config 5, second half: the fused step on an fp32 STATE (libelmk_f32.so: every fp64 field stored as fp32, all
+    arithmetic fp64 - widen on load, round on store), 10 M columns (and 1 M), both tiers.  A report: throughput, the roofline
+    against the 1 721 B/column-step bound, PMC traffic and the per-kernel register / occupancy table when the committed tables
+    belong to this build, and how far the outputs of one step are from the fp64 state's (the same step through libelmk.so on
+    the same inputs, on the device).  Never `value`: the fp64 outputs are the contract (1e-12), these are not within it."""
+    import numpy as np
+
+    from elmkernels_amd import _lib as L
+
+    if not os.path.exists(L.F32_LIB_PATH):
+        return {"error": "libelmk_f32.so not built"}
+    out = {"what": "fused step, fp32-stored state (fp64 arithmetic), libelmk_f32.so; report only", "bytes_per_column_step": ALGO_BYTES_FUSED_F32}
+    for cols_n, key in ((1_000_000, "1M"), (NORTH_STAR_COLS, "10M")):
+        for tier in ("A", "B"):
+            D, _ = build_state(cols_n, device_index, tier, seed, lib_path=L.F32_LIB_PATH)
+            for _ in range(6):  # (the canopy scheduling hints settle)
+                D.restore_fields()
+                st.timestep7_fused(D, 1800.0)
+            each = sorted(D.profile_steps(1800.0, 7, fused=True))
+            med = each[len(each) // 2]
+            ms, tot = D.profile_timestep7_fused(1800.0, 5)
+            rec = {"value": cols_n / (med * 1e-3), "unit": "gridcell-timesteps/s", "ms_per_step_median_events": med,
+                   "frac_of_fp32_fused_bound": ALGO_BYTES_FUSED_F32 * cols_n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "launch_groups_ms": {k: round(m, 4) for k, m in zip(st.KERNEL_NAMES_FUSED, ms)}, "device_state_GB": round(D.device_bytes / 1e9, 3)}
+            if cols_n == 1_000_000:
+                tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_fused_f32_tier{tier}.json")
+                rec["traffic_bytes_per_column_step"] = None if tr is None else tr / cols_n
+            D.close()
+            out.setdefault(key, {})[TIER_NAMES[tier]] = rec
+    # one step from identical inputs through both builds, on the device: how far does the fp32 state move the outputs?
+    n = 200_000
+    err = {}
+    for tier in ("A", "B"):
+        D64, _ = build_state(n, device_index, tier, seed)
+        D32, _ = build_state(n, device_index, tier, seed, lib_path=L.F32_LIB_PATH)
+        st.timestep7_fused(D64, 1800.0)
+        st.timestep7_fused(D32, 1800.0)
+        rels = []
+        worst = {}
+        for name in FP32_STUDY_FIELDS:
+            a, b = D64[name].astype(np.float64).ravel(), D32[name].astype(np.float64).ravel()
+            scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-30)
+            r = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, np.abs(a - b) / scale)
+            r = r[np.isfinite(r)]
+            rels.append(r)
+            worst[name] = float(np.percentile(r, 99)) if r.size else 0.0
+        r = np.concatenate(rels)
+        top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+        err[TIER_NAMES[tier]] = {"columns": n, "values": int(r.size), "median": float(np.median(r)), "p90": float(np.percentile(r, 90)),
+                                 "p99": float(np.percentile(r, 99)), "max": float(r.max()),
+                                 "largest_p99_fields": {k: v for k, v in top}}
+        D64.close()
+        D32.close()
+    out["relative_difference_to_fp64_state_after_one_step"] = err
+    occ = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_resources.json")
+    if os.path.exists(occ):
+        doc = json.load(open(occ))
+        if doc.get("source_hash") == kernel_source_hash():
+            out["registers_and_occupancy"] = doc["kernels"]
+    return out
+
+
+# outputs of the seven wrappers that the comparison of the two state precisions looks at
+FP32_STUDY_FIELDS = ["t_veg", "t_grnd", "h2ocan", "btran", "qflx_tran_veg", "qflx_evap_veg", "qflx_evap_soi", "qflx_evap_tot", "eflx_sh_veg",
+                     "eflx_sh_grnd", "eflx_sh_tot", "eflx_lh_tot", "cgrnd", "cgrnds", "cgrndl", "t_ref2m", "q_ref2m", "rh_ref2m", "dlrad",
+                     "ulrad", "albd", "albi", "fabd", "fabi", "sabg", "sabv", "fsa", "fsr", "frac_sno", "snow_depth", "h2osno", "qg", "thm",
+                     "tssbef", "rootr", "eff_porosity", "fwet", "fdry"]
+
+
+def pmc_traffic_total(table):
+    """Sum over all physics kernels of a committed PMC traffic table (bytes per launch), if it belongs to this build."""
+    path = os.path.join(ROOT, "profiles", table)
+    if not os.path.exists(path):
+        return None
+    doc = json.load(open(path))
+    if doc.get("source_hash") not in (None, kernel_source_hash()):
+        return None
+    return float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k != "elmk::k_copy"))
+
+
 def spawn_ranks(ngpus, argv, timeout_s=None, poll_s=0.2):
     """`python bench.py --gpus N` with no launcher: start N rank processes (one per GPU), relay rank 0's JSON line.
     The parent initialises nothing on the GPU (torch is not even imported here) and never re-executes itself.  It polls its
@@ -425,6 +509,9 @@ def main(argv=None):
     ap.add_argument("--one-gpu-value", type=float, default=None,
                     help="the 1-GPU `value` of the same configuration: with it the line carries scaling_efficiency = value / (N * that)")
     ap.add_argument("--no-soil-10m", action="store_true", help="skip the soil-column solve at 10 M columns (soil_temperature_10M)")
+    ap.add_argument("--state-f32", action="store_true",
+                    help="also measure BASELINE config 5's fp32-state variant (libelmk_f32.so: fp64 fields stored as fp32, fp64 arithmetic, "
+                         "fused step) as a separate object fp32_state_10M - reported beside the fp64 numbers, never as `value`")
     args = ap.parse_args(argv)
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -617,6 +704,10 @@ def main(argv=None):
                                "frac": gbs10 / HBM_PEAK_GBS, "bytes_per_column": SOIL_ALGO_BYTES}}
         Ds.close()
 
+    f32 = None
+    if solo and args.state_f32 and not soil:
+        f32 = fp32_state_variant(device_index, args.seed, st)
+
     if rank == 0:
         value = ncols_global * args.steps / elapsed
         tier_name = TIER_NAMES[args.tier]
@@ -729,6 +820,8 @@ def main(argv=None):
             out["north_star_10M"] = north
         if soil10 is not None:
             out["soil_temperature_10M"] = soil10
+        if f32 is not None:
+            out["fp32_state_10M"] = f32
         if not args.no_cpu_baseline and world == 1 and rehearsal is None:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(host_state, workload=args.workload)
         print(json.dumps(out), flush=True)

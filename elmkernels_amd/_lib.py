@@ -67,6 +67,7 @@ SIGNATURES = {
     "elmk_profile_timestep7": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "elmk_profile_wrapper": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "elmk_read_scratch": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64]),
+    "elmk_state_real_bytes": (C.c_int, []),
     "elmk_profile_steps": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "elmk_copy_bandwidth": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "elmk_copy_bandwidth_shape": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -98,24 +99,27 @@ class ElmkError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
+# the report-only build of BASELINE config 5 (every fp64 state field stored as fp32, same ABI): never the default
+F32_LIB_PATH = os.path.join(HERE, "libelmk_f32.so")
 
 
-def load():
-    """Load libelmk.so and declare every entry point; fails loudly when the HIP extension is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libelmk.so (or another build of the same ABI) and declare every entry point; fails loudly when the HIP
+    extension is not built."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ElmkError(
-            f"{LIB_PATH} not found: build the HIP extension first "
+            f"{path} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C elmkernels_amd/csrc). "
             "elmkernels_amd has no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale w.r.t. include/elmk.h
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib

@@ -35,6 +35,15 @@ const FieldDesc g_fields[ELMK_NUM_FIELDS] = {
 };
 
 inline int elem_size(int dtype) { return dtype == ELMK_F64 ? 8 : (dtype == ELMK_U8 ? 1 : 4); }
+// bytes of one element as it is STORED on the device: the report-only ELMK_STATE_F32 build (libelmk_f32.so, BASELINE config 5)
+// keeps every fp64 state field as fp32 (elmk_dev.h: field_of); the C ABI still speaks double
+#ifdef ELMK_STATE_F32
+constexpr bool kStateF32 = true;
+#else
+constexpr bool kStateF32 = false;
+#endif
+inline int store_size(int dtype) { return (kStateF32 && dtype == ELMK_F64) ? 4 : elem_size(dtype); }
+inline int store_dtype(int dtype) { return (kStateF32 && dtype == ELMK_F64) ? ELMK_F32_STORED : dtype; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 thread_local std::string g_create_error;
@@ -198,7 +207,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   size_t foff[ELMK_NUM_FIELDS];
   for (int f = 0; f < ELMK_NUM_FIELDS; f++) {
     foff[f] = off;
-    off += align_up((size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype), 256);
+    off += align_up((size_t)g_fields[f].nlev * (size_t)ctx->ld * store_size(g_fields[f].dtype), 256);
   }
   ctx->arena_bytes = off;
   if (hip_fail(ctx, hipMalloc((void**)&ctx->arena, off), "hipMalloc(state arena)")) return fail(ELMK_E_NOMEM);
@@ -280,7 +289,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   }
   {
     int f = 0;
-#define ELMK_FIELD(name, T, nlev) h.name = (gptr<ctype_of<ELMK_##T>::type>)ctx->fptr[f++];
+#define ELMK_FIELD(name, T, nlev) h.name = field_of<ELMK_##T>::from(ctx->fptr[f++]);
 #include "elmk_fields.def"
 #undef ELMK_FIELD
     h.err_flags = (gptr<uint32_t>)ctx->fptr[f];
@@ -380,13 +389,34 @@ int elmk_field_info(int field, int* nlev, int* dtype)
 // ---------------------------------------------------------------------------------------------------
 // data movement
 // ---------------------------------------------------------------------------------------------------
+static int xfer_stored(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout, bool up);
+
 static int xfer(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout, bool up)
 {
   if (int rc = enter(ctx)) return rc;
   if (!field_ok(field) || (!host && n > 0) || col0 < 0 || n < 0 || col0 + n > ctx->ncols)
     return invalid(ctx, "elmk_upload/download: bad field or column range");
   if (n == 0) return ELMK_OK;
-  const int es = elem_size(g_fields[field].dtype), nlev = g_fields[field].nlev;
+  if (kStateF32 && g_fields[field].dtype == ELMK_F64) {
+    // fp32-state build: the caller's doubles are rounded to the stored fp32 on the way in and widened on the way out (on the
+    // host: this build is a measurement variant, its benchmark tiles a small uploaded block on the device)
+    const size_t cnt = (size_t)n * (size_t)g_fields[field].nlev;
+    std::vector<float> tmp(cnt);
+    double* h = (double*)host;
+    if (up)
+      for (size_t i = 0; i < cnt; i++) tmp[i] = (float)h[i];
+    const int rc = xfer_stored(ctx, field, tmp.data(), col0, n, layout, up);
+    if (rc == ELMK_OK && !up)
+      for (size_t i = 0; i < cnt; i++) h[i] = (double)tmp[i];
+    return rc;
+  }
+  return xfer_stored(ctx, field, host, col0, n, layout, up);
+}
+
+// host elements already in the stored element type
+static int xfer_stored(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout, bool up)
+{
+  const int es = store_size(g_fields[field].dtype), nlev = g_fields[field].nlev;
   char* dev = (char*)ctx->fptr[field];
   if (layout == ELMK_LAYOUT_SOA || nlev == 1) {
     // rows of n elements <-> rows of ld elements
@@ -422,6 +452,14 @@ static int xfer(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, i
 
 int elmk_upload(elmk_ctx* ctx, int field, const void* host, int64_t col0, int64_t n, int layout)
 {
+  // snl indexes the level arrays (top = nlevsno - snl) in every snow and soil kernel, in global memory and in LDS packs: a
+  // value outside 0..nlevsno is refused here, at the one door host data comes through, instead of being read out of bounds on
+  // the device (the reference has the same undefined behaviour, but no such door)
+  if (ctx && host && n > 0 && field_ok(field) && field == ELMK_FIELD_snl) {
+    const int32_t* v = (const int32_t*)host;
+    for (int64_t i = 0; i < n; i++)
+      if (v[i] < 0 || v[i] > NLEVSNO) return invalid(ctx, "elmk_upload: snl outside 0..nlevsno");
+  }
   return xfer(ctx, field, const_cast<void*>(host), col0, n, layout, true);
 }
 int elmk_download(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout)
@@ -433,7 +471,7 @@ int elmk_fill(elmk_ctx* ctx, int field, double value)
 {
   if (int rc = enter(ctx)) return rc;
   if (!field_ok(field)) return invalid(ctx, "elmk_fill: bad field");
-  launch_fill(ctx->fptr[field], g_fields[field].dtype, g_fields[field].nlev, ctx->ld, ctx->ncols, value, ctx->stream);
+  launch_fill(ctx->fptr[field], store_dtype(g_fields[field].dtype), g_fields[field].nlev, ctx->ld, ctx->ncols, value, ctx->stream);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }
@@ -454,7 +492,7 @@ int elmk_tile_columns(elmk_ctx* ctx, int64_t nbase, uint64_t seed, int nrules, c
         amp = rules[r].amp;
       }
     }
-    launch_tile(ctx->fptr[f], g_fields[f].dtype, g_fields[f].nlev, ctx->ld, ctx->ncols, nbase, seed, f, mode, amp,
+    launch_tile(ctx->fptr[f], store_dtype(g_fields[f].dtype), g_fields[f].nlev, ctx->ld, ctx->ncols, nbase, seed, f, mode, amp,
                 ctx->stream);
   }
   HIPCHK(hipGetLastError());
@@ -481,7 +519,7 @@ int elmk_snapshot_fields(elmk_ctx* ctx, const int* fields, int nfields)
   };
   for (int i = 0; i < nfields; i++) {
     const int f = fields[i];
-    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype);
+    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * store_size(g_fields[f].dtype);
     char* b = nullptr;
     if (hip_fail(ctx, hipMalloc((void**)&b, bytes), "hipMalloc(snapshot)")) {
       drop();
@@ -507,7 +545,7 @@ int elmk_restore_fields(elmk_ctx* ctx)
   if (int rc = enter(ctx)) return rc;
   for (size_t i = 0; i < ctx->snap_fields.size(); i++) {
     const int f = ctx->snap_fields[i];
-    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * elem_size(g_fields[f].dtype);
+    const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * store_size(g_fields[f].dtype);
     // a plain streaming kernel: hipMemcpyAsync device-to-device goes through the SDMA engines here (~80 GB/s)
     launch_copy((const double*)ctx->snap_bufs[i], (double*)ctx->fptr[f], (int64_t)(bytes / 8), ctx->stream);
   }
@@ -826,6 +864,8 @@ int run_graph(elmk_ctx* ctx, GraphSlot& g, stage_fn fn, int nstage, double dt)
 {
   if (!g.exec || g.dt != dt || g.stream != ctx->stream) {
     if (g.exec) {
+      // (dt or the stream changed: the old executable may still be running its last launch)
+      if (g.stream) HIPCHK(hipStreamSynchronize(g.stream));
       (void)hipGraphExecDestroy(g.exec);
       g.exec = nullptr;
     }
@@ -1045,6 +1085,8 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
     for (int64_t i = 0; i < count; i++) ((int32_t*)host)[i] >>= 16;
   return ELMK_OK;
 }
+
+int elmk_state_real_bytes(void) { return kStateF32 ? 4 : 8; }
 
 int elmk_copy_bandwidth(elmk_ctx* ctx, int64_t bytes, int iters, double* gbytes_per_s)
 {

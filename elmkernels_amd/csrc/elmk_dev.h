@@ -80,6 +80,40 @@ template <> struct ctype_of<ELMK_F64> { using type = double; };
 template <> struct ctype_of<ELMK_I32> { using type = int32_t; };
 template <> struct ctype_of<ELMK_U8> { using type = uint8_t; };
 
+// How a state field of elmk_fields.def is held on the device.  Product build: a global pointer to its element type.
+// ELMK_STATE_F32 (the report-only build of BASELINE config 5, libelmk_f32.so): every fp64 field is STORED as fp32 - half the
+// bytes per column - while all arithmetic stays fp64: an access widens on load and rounds to nearest on store, through a
+// reference object, so the kernels' source is the same text in both builds.  Scratch (queue records, work arrays) and the
+// shared parameter tables stay fp64 in both.
+template <int T> struct field_of {
+  using type = gptr<typename ctype_of<T>::type>;
+  static __host__ __device__ type from(void* p) { return (type)p; }
+};
+#ifdef ELMK_STATE_F32
+typedef float state_real;
+struct F32Ref {
+  gptr<float> p;
+  __device__ __forceinline__ operator double() const { return (double)*p; }
+  __device__ __forceinline__ const F32Ref& operator=(double v) const { *p = (float)v; return *this; }
+  __device__ __forceinline__ const F32Ref& operator=(const F32Ref& o) const { *p = *o.p; return *this; }
+  __device__ __forceinline__ const F32Ref& operator+=(double v) const { *p = (float)((double)*p + v); return *this; }
+  __device__ __forceinline__ const F32Ref& operator-=(double v) const { *p = (float)((double)*p - v); return *this; }
+  __device__ __forceinline__ const F32Ref& operator*=(double v) const { *p = (float)((double)*p * v); return *this; }
+};
+struct F32Field {
+  gptr<float> p;
+  __device__ __forceinline__ F32Ref operator[](int64_t i) const { return F32Ref{p + i}; }
+  __device__ __forceinline__ F32Field operator+(int64_t off) const { return F32Field{p + off}; }
+};
+template <> struct field_of<ELMK_F64> {
+  using type = F32Field;
+  static __host__ __device__ type from(void* p) { return F32Field{(gptr<float>)p}; }
+};
+#else
+typedef double state_real;
+#endif
+typedef field_of<ELMK_F64>::type dfield;  // an fp64 state field (or a position inside one), whatever it is stored as
+
 // indices into one row of the PFT photosynthesis table (member order of ELM::PFTDataPSN, pft_data.h:20-24)
 enum : int {
   P_fnr, P_act25, P_kcha, P_koha, P_cpha, P_vcmaxha, P_jmaxha, P_tpuha, P_lmrha, P_vcmaxhd, P_jmaxhd, P_tpuhd,
@@ -201,7 +235,7 @@ struct DevState {
   gptr<int8_t> cf_cls;      // scheduling class of each column as k_fz_prep counted it (fused step)
   gptr<uint32_t> cf_blk;    // CF_NCLS x cf_nblk: per-workgroup class counts, then exclusive offsets
   int64_t cf_nblk;     // workgroups of 256 columns
-#define ELMK_FIELD(name, T, nlev) gptr<ctype_of<ELMK_##T>::type> name;
+#define ELMK_FIELD(name, T, nlev) field_of<ELMK_##T>::type name;
 #include "elmk_fields.def"
 #undef ELMK_FIELD
   gptr<uint32_t> err_flags;

@@ -58,6 +58,8 @@ void launch_cols_to_soa(const void* staging, void* field, int elem, int nlev, in
                         hipStream_t st);
 void launch_soa_to_cols(const void* field, void* staging, int elem, int nlev, int64_t ld, int64_t col0, int64_t n,
                         hipStream_t st);
+// storage code of an fp64 state field kept as fp32 (ELMK_STATE_F32 builds), beside the public elmk_dtype values
+constexpr int ELMK_F32_STORED = 16;
 void launch_fill(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, double value, hipStream_t st);
 void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, int64_t nbase, uint64_t seed,
                  int field_id, int mode, double amp, hipStream_t st);

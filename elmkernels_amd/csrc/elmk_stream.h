@@ -86,8 +86,14 @@ __device__ __forceinline__ double pond_fraction(const double sigma, const double
   return 0.5 * (1.0 + elmk_erf(d / (sigma * sqrt(2.0))));
 }
 // All threads of the (256-thread) workgroup call this; returns the thread's own frac_h2osfc if it asked for one.
+#ifndef ELMK_POND_POOL
+#define ELMK_POND_POOL 1  // 0: every column solves in its own lane (development A/B)
+#endif
 __device__ __forceinline__ double block_pond_fraction(const bool need, const double sigma, const double h2osfc)
 {
+#if !ELMK_POND_POOL
+  return need ? pond_fraction(sigma, h2osfc) : 0.0;
+#endif
   __shared__ double s_sigma[256], s_h2osfc[256], s_frac[256];
   __shared__ uint32_t s_owner[256];
   __shared__ uint32_t s_n;
@@ -547,7 +553,9 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
 // old_ground_temp :9, ground_temp :32, calc_soilalpha :51, calc_soilbeta :133 (-> surface_resistance_impl.hh:9),
 // humidities :143, ground_properties :205, forcing_height :260, init_energy_fluxes :299 of canopy_temperature_impl.hh
 // =====================================================================================================
-template <bool FUSED>
+// SOIL_COPIED: the fused step's early kernel (k_fz_pre, k_canopy_fluxes.hip) has already saved the soil levels of t_soisno
+// into tssbef - canopy_hydrology, which runs between the two, only ever writes snow levels of t_soisno
+template <bool FUSED, bool SOIL_COPIED = false>
 __device__ __forceinline__ void canopy_temperature_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
                                                        ColFwd& w)
 {
@@ -560,13 +568,13 @@ __device__ __forceinline__ void canopy_temperature_col(const DevState* __restric
   double t_top = 0.0, t_soi0 = 0.0;
   const bool wall = (L.ctype == icol_sunwall || L.ctype == icol_shadewall || L.ctype == icol_roof);
 #pragma unroll
-  for (int i = 0; i < NLEVTOT; i++) {
+  for (int i = 0; i < (SOIL_COPIED ? NLEVSNO + 1 : NLEVTOT); i++) {
     const double t = LV(t_soisno, i);
     if (i <= NLEVSNO) {
       if (i == top) t_top = t;
       if (i == NLEVSNO) t_soi0 = t;
     }
-    if (!L.lakpoi) LV(tssbef, i) = (wall && i > 5) ? SPVAL : t;
+    if (!L.lakpoi && !(SOIL_COPIED && i >= NLEVSNO)) LV(tssbef, i) = (wall && i > 5) ? SPVAL : t;
   }
   if (!L.lakpoi) S->t_h2osfc_bef[c] = t_h2osfc;
 

@@ -613,8 +613,9 @@ __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S
 // Queue position of this thread's column: slice of (class, workgroup) from the count kernel (k_cf_count, or k_fz_prep in
 // the fused step), then (wave, lane) order inside the workgroup.  All 256 threads of the workgroup call it (one barrier);
 // cls < 0: not vegetated -> -1.  Thread 0 of workgroup 0 publishes the queue length.
-__device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict__ S, const int cls)
+__device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict__ S, const int cls, const int64_t tile = -1)
 {
+  const int64_t blk = tile >= 0 ? tile : (int64_t)blockIdx.x;  // the 256-column tile this workgroup is placing
   __shared__ uint32_t s_w[4][CF_NCLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t rank = 0u;
@@ -633,12 +634,12 @@ __device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict_
     if (k == cls) mine = start;
     start += CF_CLASS_COUNT(S, k);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blk == 0 && threadIdx.x == 0) {
     ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = start;
     ELMK_LIST_HEAD(S, LIST_CF_QUEUE) = 0u;
   }
   if (cls >= 0) {
-    uint32_t off = mine + S->cf_blk[(int64_t)cls * S->cf_nblk + blockIdx.x];
+    uint32_t off = mine + S->cf_blk[(int64_t)cls * S->cf_nblk + blk];
     for (int w = 0; w < wave; w++) off += s_w[w][cls];
     pos = (int64_t)off + rank;
   }
@@ -650,35 +651,17 @@ __device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict_
 // earlier bodies of the same pass produced come through ColFwd).  pos: the column's queue position (-1: not vegetated).
 // given: bit 0 / 1 / 2 = forc_rho / forc_po2 / forc_pco2 come from S->cf_given (elmk_canopy_fluxes_given) instead of being
 // derived from the forcing as the wrapper does (canopy_fluxes_kokkos.cc:47-49)
-template <bool FUSED>
-__device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                            const int64_t pos, const ColFwd& w, const int given = 0)
+// soil_moist_stress (soil_moist_stress_impl.hh:62-133) of one vegetated column: effective porosity, liquid volume and root
+// moisture stress of the 15 soil levels -> eff_porosity, rootr, btran (state and queue record).  liq0: the liquid water of the
+// top soil level as canopy_fluxes sees it (in the fused step's early kernel: what canopy_hydrology is about to leave there).
+__device__ __forceinline__ void cf_root_stress_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const int64_t pos,
+                                                   const double liq0)
 {
-  const bool inside = true, veg = pos >= 0;
-  if (inside && !veg) {
-    S->cf_niter[c] &= (int32_t)0xFFFF0000;  // trips of this call: 0 (not vegetated); the scheduling hint stays
-    if (!L.urbpoi) {
-      S->btran[c] = 0.0;
-      S->t_veg[c] = FW(forc_tbot, S->forc_tbot[c]);
-#pragma unroll
-      for (int i = 0; i < NLEVGRND; i++) LV(rootr, i) = 0.0;
-    }
-    // (the cgrnd* = 0 of this branch, compute_flux :470-474, is written by k_cf_finish: in the fused step this body runs
-    // BEFORE the bare-ground flux list, whose cgrnd* of the same columns the reference's call order overwrites)
-  }
-  if (!veg) return;
-
-  // record fields are stored as soon as they are final (PUT), so few of them are live at any time
-  CfRec r;
-  const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
-#define PUT(n) rec[REC_##n * 8] = r.n;
-  const int snl = FW(snl, S->snl[c]);
   const int vtype = S->vtype[c];
   const double* __restrict__ P = S->pft_psn[vtype];
   const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
   double btran = 0.0;  // btran0
   double rootr[NLEVGRND];
-  double t_soi0 = 0.0;
 #pragma unroll
   for (int i = 0; i < NLEVGRND; i++) {
     const double watsat = LV(watsat, i);
@@ -688,10 +671,10 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
     const double eff_por = watsat - vol_ice;
     LV(eff_porosity, i) = eff_por;
     // calc_volumetric_h2oliq (:77-86)
-    const double liqvol = dmin(eff_por, (LV(h2osoi_liq, NLEVSNO + i) / (dzi * DENH2O)));
+    const double liq = (i == 0) ? liq0 : (double)LV(h2osoi_liq, NLEVSNO + i);
+    const double liqvol = dmin(eff_por, (liq / (dzi * DENH2O)));
     // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
     const double tsoi = LV(t_soisno, NLEVSNO + i);
-    if (i == 0) t_soi0 = tsoi;
     if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
       rootr[i] = 0.0;
     } else {
@@ -714,8 +697,39 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
     LV(rootr, i) = q;
   }
   S->btran[c] = btran;
-  r.btran = btran;
-  PUT(btran)
+  (S->cf_rec + CF_REC_BASE(pos))[REC_btran * 8] = btran;
+}
+
+// ROOT_DONE: the fused step's early kernel (k_fz_pre) has already done cf_root_stress_col and the bare branch's rootr / btran
+template <bool FUSED, bool ROOT_DONE = false>
+__device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
+                                            const int64_t pos, const ColFwd& w, const int given = 0)
+{
+  const bool inside = true, veg = pos >= 0;
+  if (inside && !veg) {
+    S->cf_niter[c] &= (int32_t)0xFFFF0000;  // trips of this call: 0 (not vegetated); the scheduling hint stays
+    if (!L.urbpoi) {
+      S->t_veg[c] = FW(forc_tbot, S->forc_tbot[c]);
+      if (!ROOT_DONE) {
+        S->btran[c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NLEVGRND; i++) LV(rootr, i) = 0.0;
+      }
+    }
+    // (the cgrnd* = 0 of this branch, compute_flux :470-474, is written by k_cf_finish: in the fused step this body runs
+    // BEFORE the bare-ground flux list, whose cgrnd* of the same columns the reference's call order overwrites)
+  }
+  if (!veg) return;
+
+  // record fields are stored as soon as they are final (PUT), so few of them are live at any time
+  CfRec r;
+  const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
+#define PUT(n) rec[REC_##n * 8] = r.n;
+  const int snl = FW(snl, S->snl[c]);
+  const int vtype = S->vtype[c];
+  const double* __restrict__ P = S->pft_psn[vtype];
+  if (!ROOT_DONE) cf_root_stress_col(S, c, ld, pos, LV(h2osoi_liq, NLEVSNO));
+  const double t_soi0 = LV(t_soisno, NLEVSNO);
   const double t_top = (snl > 0) ? LV(t_soisno, NLEVSNO - snl) : t_soi0;
 
   // canopy roughness blend (canopy_fluxes_impl.hh:141-147)
@@ -1601,6 +1615,57 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
   }
 }
 
+// k_fz_pre - the part of the streaming pass that depends on nothing the albedo stage or canopy_hydrology produce, as a kernel
+// of its own that runs BESIDE the albedo stage on a side stream: SNICAR and the two-stream solution are bound by fp64 issue,
+// this kernel by HBM, and the two kinds of work share the CUs.  Per column: the queue position of the canopy_fluxes record,
+// the root moisture stress of the 15 soil levels (soil_moist_stress: 105 level values read, rootr / eff_porosity written,
+// fifteen pow) and old_ground_temp's copy of the soil levels of t_soisno into tssbef - 1.4 KB of the 3.1 KB per column that
+// k_fz_stream used to move.  What lies between this kernel and k_fz_stream in the reference's call order touches none of it
+// with one exception: fraction_h2osfc folds a vanishing pond (h2osfc <= 1e-8) into the top soil layer's liquid
+// (canopy_hydrology_impl.hh:334-337), which calc_volumetric_h2oliq then reads - the same sum is formed here for that level.
+#ifndef FZ_PRE_WGS_PER_CU
+#define FZ_PRE_WGS_PER_CU 0  // > 0: a persistent grid of that many workgroups per CU walks the tiles (leaves room for the albedo stage)
+#endif
+__device__ __forceinline__ void fz_pre_tile(const DevState* __restrict__ S, const int64_t tile);
+__global__ __launch_bounds__(256) void k_fz_pre(const DevState* __restrict__ S)
+{
+  elmk_math_lds_init<false>();
+  if (S->land.lakpoi) {  // uniform: neither canopy_temperature's copy nor canopy_fluxes does anything on lake land units
+    if (blockIdx.x == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+    return;
+  }
+  for (int64_t tile = blockIdx.x; tile < S->cf_nblk; tile += gridDim.x) {
+    fz_pre_tile(S, tile);
+    __syncthreads();  // (cf_queue_position's LDS counters are reused by the next tile)
+  }
+}
+__device__ __forceinline__ void fz_pre_tile(const DevState* __restrict__ S, const int64_t tile)
+{
+  const int64_t c = tile * blockDim.x + threadIdx.x;
+  const int64_t ld = S->ld;
+  const Land L = S->land;
+  const bool inside = c < S->ncols;
+  // queue position of the canopy_fluxes record (every thread of the workgroup takes part in the barrier inside)
+  const int64_t pos = cf_queue_position(S, inside ? (int)S->cf_cls[c] : -1, tile);
+  if (!inside) return;
+  S->cf_pos[c] = (int32_t)pos;
+  const bool wall = (L.ctype == icol_sunwall || L.ctype == icol_shadewall || L.ctype == icol_roof);
+#pragma unroll
+  for (int i = NLEVSNO; i < NLEVTOT; i++) LV(tssbef, i) = (wall && i > 5) ? SPVAL : (double)LV(t_soisno, i);
+  if (pos >= 0) {
+    double liq0 = LV(h2osoi_liq, NLEVSNO);
+    if (L.ltype == istsoil || L.ltype == istcrop) {
+      const double h2osfc = S->h2osfc[c];
+      if (!(h2osfc > 1.e-8)) liq0 = liq0 + h2osfc;
+    }
+    cf_root_stress_col(S, c, ld, pos, liq0);
+  } else if (!L.urbpoi) {
+    S->btran[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NLEVGRND; i++) LV(rootr, i) = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict__ S, double dtime)
 {
   elmk_math_lds_init<false>();
@@ -1608,18 +1673,11 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
   const int64_t ld = S->ld;
   const Land L = S->land;
   const bool inside = c < S->ncols;
-  // queue position of the canopy_fluxes record (every thread of the workgroup takes part in the barrier inside)
-  int64_t pos = -1;
-  if (!L.lakpoi) {
-    pos = cf_queue_position(S, inside ? (int)S->cf_cls[c] : -1);
-  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
-  }
   ColFwd w;
   canopy_hydrology_col<true>(S, c, ld, L, dtime, w, inside);  // (every thread: the pond solves are pooled per workgroup)
   if (inside) {
     surface_radiation_col<true>(S, c, ld, L, w);
-    canopy_temperature_col<true>(S, c, ld, L, w);
+    canopy_temperature_col<true, true>(S, c, ld, L, w);
   }
   // bareground_fluxes, streaming stage (k_bg_main): compute_flux's unconditional cgrnd reset and the list of bare columns
   if (!L.lakpoi) {
@@ -1630,11 +1688,8 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
     }
     const bool bare = inside && !L.urbpoi && w.fvn == 0;
     block_classify_append<1>(S->lists, ld, S->counters, LIST_BG, bare ? 0 : -1, (int32_t)c);
-    // canopy_fluxes up to the iteration
-    if (inside) {
-      S->cf_pos[c] = (int32_t)pos;
-      cf_init_col<true>(S, c, ld, L, pos, w);
-    }
+    // canopy_fluxes up to the iteration (queue position and root moisture stress: k_fz_pre)
+    if (inside) cf_init_col<true, true>(S, c, ld, L, (int64_t)S->cf_pos[c], w);
   }
 }
 
@@ -1644,7 +1699,21 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
   const unsigned nblk = (unsigned)((n + 255) / 256);
   switch (stage) {
     case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + FZ_PREP_TILES - 1) / FZ_PREP_TILES), dim3(256), 0, st, S); break;
-    case 1: launch_albedo_snicar(S, n, st, side, false); break;
+    case 1:
+      if (n >= 262144) {
+        // k_fz_pre (memory-bound) beside the albedo stage (fp64-issue-bound) on a side stream; joined before k_fz_stream
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
+        hipLaunchKernelGGL(k_fz_pre, dim3(FZ_PRE_WGS_PER_CU > 0 && nblk > 256u * FZ_PRE_WGS_PER_CU ? 256u * FZ_PRE_WGS_PER_CU : nblk), dim3(256), 0,
+                           side->s[0], S);
+        (void)hipEventRecord(side->join[0], side->s[0]);
+        launch_albedo_snicar(S, n, st, side, false);
+        (void)hipStreamWaitEvent(st, side->join[0], 0);
+      } else {  // (few columns: the SNICAR queues themselves fork onto the side streams)
+        hipLaunchKernelGGL(k_fz_pre, dim3(nblk), dim3(256), 0, st, S);
+        launch_albedo_snicar(S, n, st, side, false);
+      }
+      break;
     case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;
     case 3: launch_bareground_list(S, n, st); break;
     default: {

@@ -620,8 +620,8 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
   const Land L = S->land;
   const int lane = (int)threadIdx.x;
   // the pack: global rows -> LDS (all loads independent: one batch in flight)
-  const gptr<double> g6[5] = {S->h2osoi_liq + c, S->h2osoi_ice + c, S->t_soisno + c, S->dz + c, S->zisoi + c};
-  const gptr<double> g5[2 + NAER] = {S->zsoi + c, S->snw_rds + c, S->mss_bcphi + c, S->mss_bcpho + c,
+  const dfield g6[5] = {S->h2osoi_liq + c, S->h2osoi_ice + c, S->t_soisno + c, S->dz + c, S->zisoi + c};
+  const dfield g5[2 + NAER] = {S->zsoi + c, S->snw_rds + c, S->mss_bcphi + c, S->mss_bcpho + c,
                                      S->mss_dst1 + c, S->mss_dst2 + c, S->mss_dst3 + c, S->mss_dst4 + c};
 #pragma unroll
   for (int f = 0; f < 5; f++)
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
   // update_aerosol_mass_and_concen (aerosol_physics_impl.hh:10-31, :67-106)
   {
     const int snotop = NLEVSNO - snl;
-    const gptr<double> cnc[NAER] = {S->cnc_bcphi + c, S->cnc_bcpho + c, S->cnc_dst1 + c, S->cnc_dst2 + c, S->cnc_dst3 + c, S->cnc_dst4 + c};
+    const dfield cnc[NAER] = {S->cnc_bcphi + c, S->cnc_bcpho + c, S->cnc_dst1 + c, S->cnc_dst2 + c, S->cnc_dst3 + c, S->cnc_dst4 + c};
 #pragma unroll
     for (int sl = 0; sl < NLEVSNO; sl++) {
       const double snowmass = (sl < snotop) ? 1.e-12 : AT(K.ice, sl) + AT(K.liq, sl);

@@ -95,6 +95,8 @@ void launch_fill(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, do
   const dim3 grid((unsigned)((ncols + 255) / 256)), block(256);
   if (dtype == ELMK_F64)
     hipLaunchKernelGGL(k_fill<double>, grid, block, 0, st, (double*)field, nlev, ld, ncols, value);
+  else if (dtype == ELMK_F32_STORED)
+    hipLaunchKernelGGL(k_fill<float>, grid, block, 0, st, (float*)field, nlev, ld, ncols, (float)value);
   else if (dtype == ELMK_I32)
     hipLaunchKernelGGL(k_fill<int32_t>, grid, block, 0, st, (int32_t*)field, nlev, ld, ncols, (int32_t)value);
   else if (dtype == ELMK_U32)
@@ -143,6 +145,8 @@ void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, in
   if (dtype == ELMK_F64)
     hipLaunchKernelGGL(k_tile<double>, grid, block, 0, st, (double*)field, nlev, ld, ncols, nbase, seed, field_id, mode,
                        amp);
+  else if (dtype == ELMK_F32_STORED)
+    hipLaunchKernelGGL(k_tile<float>, grid, block, 0, st, (float*)field, nlev, ld, ncols, nbase, seed, field_id, mode, amp);
   else if (dtype == ELMK_I32 || dtype == ELMK_U32)
     hipLaunchKernelGGL(k_tile<int32_t>, grid, block, 0, st, (int32_t*)field, nlev, ld, ncols, nbase, seed, field_id, -1,
                        0.0);

@@ -51,8 +51,8 @@ def pack_pft(pft):
 
 
 class ELMState:
-    def __init__(self, ncols, device=0):
-        self.lib = L.load()
+    def __init__(self, ncols, device=0, lib_path=None):
+        self.lib = L.load(lib_path)
         self.ncols = int(ncols)
         self.device = int(device)
         h = C.c_void_p()

@@ -172,6 +172,10 @@ int elmk_num_fields(void);
 const char *elmk_field_name(int field);
 int elmk_field_id(const char *name); /* -1 if unknown */
 int elmk_field_info(int field, int *nlev, int *dtype);
+/* bytes the device keeps per element of an fp64 field: 8 in the product (libelmk.so); 4 in libelmk_f32.so, the report-only
+ * build of BASELINE config 5 ("fp32 state": every fp64 field stored as fp32, all arithmetic fp64, widen on load / round on
+ * store).  The ABI is the same in both: uploads and downloads speak double. */
+int elmk_state_real_bytes(void);
 
 /* ---- data movement -------------------------------------------------------------------------- */
 /* columns [col0, col0+n) of one field; host buffer holds n*nlev elements in the given layout */

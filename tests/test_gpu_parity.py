@@ -37,6 +37,8 @@ def test_roundtrip_layouts():
     for name in ("t_soisno", "zisoi", "albd", "snl", "veg_active", "forc_tbot", "snw_rds"):
         fid, nlev, dt = D.fields[name]
         a = (rng.random((1000, nlev)) * 100).astype(dt)
+        if name == "snl":
+            a %= 6  # (elmk_upload refuses a number of snow layers outside 0..5)
         D.upload(name, a)
         assert np.array_equal(D.download(name).reshape(1000, nlev), a), name
         soa = D.download(name, layout=st.LAYOUT_SOA).reshape(nlev, 1000)
@@ -359,15 +361,20 @@ def test_other_land_units():
 
 
 def test_fixture_steps_on_device():
-    """The reference's own fixture inputs (one step per column), every module, HIP vs oracle at 1e-12 and HIP vs
-    the ELM _OUT records at 1e-9 (the reference itself is only 3.5e-10 close on CanopyFluxes)."""
+    """The reference's own fixture inputs (one step per column), the five streaming modules through the HIP kernels:
+    HIP vs the ELM _OUT records with the reference's own comparison, ELM::IO::IsAlmostEqual (relative 1e-15 / absolute 1e-20,
+    src/utils/read_test_input.hh:17-24) - the bar the reference's tests hold and the oracle meets on the CPU - and HIP vs the
+    oracle on the same steps bit for bit."""
+    from oracle import oracle as O
+
     pft, optics = synth.load_params()
-    for module, run in (
-        ("CanopyHydrology", lambda D: (st.kokkos_canopy_hydrology(D, DT), st.kokkos_frac_wet(D))),
-        ("SurfaceRadiation", lambda D: st.kokkos_surface_radiation(D)),
-        ("CanopySunShadeFractions", lambda D: st.kokkos_surface_radiation(D)),
-        ("CanopyTemperature", lambda D: st.kokkos_canopy_temperature(D)),
-        ("SurfaceAlbedo", lambda D: st.kokkos_albedo_snicar(D)),
+    for module, run, run_oracle in (
+        ("CanopyHydrology", lambda D: (st.kokkos_canopy_hydrology(D, DT), st.kokkos_frac_wet(D)),
+         lambda S: (S.canopy_hydrology(DT), S.frac_wet())),
+        ("SurfaceRadiation", lambda D: st.kokkos_surface_radiation(D), lambda S: S.surface_radiation()),
+        ("CanopySunShadeFractions", lambda D: st.kokkos_surface_radiation(D), lambda S: S.surface_radiation()),
+        ("CanopyTemperature", lambda D: st.kokkos_canopy_temperature(D), lambda S: S.canopy_temperature()),
+        ("SurfaceAlbedo", lambda D: st.kokkos_albedo_snicar(D), lambda S: S.albedo_snicar()),
     ):
         d = F.load(module)
         rows = F.select_steps(d, module)
@@ -375,29 +382,175 @@ def test_fixture_steps_on_device():
         D.set_pft(pft)
         D.set_snicar(optics)
         D.set_land(**F.TEST_LAND)
+        S = O.OracleState(len(rows))
+        S.load_params(pft, optics)
+        S.set_scalars(**F.TEST_LAND)
         nlev = {k: v[1] for k, v in D.fields.items()}
         fin, oin = F.split(d, "in/", rows, nlev)
         fout, _ = F.split(d, "out/", rows, nlev)
+        F.fill_state(S, fin)
         for k, v in fin.items():
             D[k] = np.nan_to_num(v, nan=0.0) if D.fields[k][2] != np.float64 else v
         D["vtype"] = np.full(len(rows), 12, np.int32)
         D["veg_active"] = np.ones(len(rows), np.uint8)
+        S["vtype"][:] = 12
+        S["veg_active"][:] = 1
         if module == "CanopyHydrology":
-            D.set_scalars(oldfflag=int(oin["oldfflag"][0, 0]), dewmx=float(oin["dewmx"][0, 0]))
+            sc = dict(oldfflag=int(oin["oldfflag"][0, 0]), dewmx=float(oin["dewmx"][0, 0]))
+            D.set_scalars(**sc)
+            S.set_scalars(**sc)
         if module == "CanopyTemperature":
             for k in "utq":
                 D[f"forc_hgt_{k}_patch"] = oin[f"forc_hgt_{k}"][:, 0]
+                S[f"forc_hgt_{k}_patch"][:] = oin[f"forc_hgt_{k}"][:, 0]
         if module == "SurfaceAlbedo":
             D.set_soilcolor(np.tile(oin["albsat"][0], (20, 1)), np.tile(oin["albdry"][0], (20, 1)))
             D["isoicol"] = np.full(len(rows), 3, np.int32)
+            S.albsat[:] = oin["albsat"][0]
+            S.albdry[:] = oin["albdry"][0]
+            S["isoicol"][:] = 3
         run(D)
+        run_oracle(S)
+        total = 0
         for name, exp in fout.items():
             if module == "SurfaceAlbedo" and name in ("fabd_sun", "fabd_sha"):
                 continue  # wrapper-local in the reference, never stored in the state
             got = D[name].reshape(len(rows), -1).astype(np.float64)
-            r = np.where(np.isnan(exp), 0.0, F.rel_err(got, exp, floor=1e-18))
-            assert r.max() < 1e-9, f"{module}.{name}: {r.max():.3e}"
+            ok = F.almost_equal(got, exp) | np.isnan(exp)
+            total += ok.size
+            assert ok.all(), f"{module}.{name}: {int((~ok).sum())} values beyond IsAlmostEqual, worst {float(np.where(ok, 0.0, F.rel_err(got, exp)).max()):.3e}"
+        assert total >= 700, (module, total)
+        # ... and the device against the oracle on the same steps: every field the module writes, bit for bit
+        worst, bad = H.compare_states(D, S, names=[n for n in fout if n in S.fields and n in D.fields], bitwise=True)
+        assert not bad, f"{module}: HIP vs oracle {bad}"
         D.close()
+
+
+def test_the_gpu_run_holds_the_bitwise_bar():
+    """On the GPU selection the device-vs-oracle comparisons must not silently fall back from bit identity to the 1e-12
+    tolerance (a missing gcc, a failed probe build or another host libm would do that, and the suite would still be green).
+    ELMK_ALLOW_TOLERANCE=1 opts in to the fallback explicitly (a GPU host with another libm)."""
+    import os
+
+    from tests import _parity_mode as M
+
+    print("elmk parity bar on this host:", M.REASON)
+    if os.environ.get("ELMK_ALLOW_TOLERANCE") == "1":
+        return
+    assert M.BITWISE_VALID, M.REASON
+
+
+def test_snl_outside_its_range_is_refused_at_upload():
+    """snl indexes the level arrays in every snow / soil kernel: a value outside 0..5 never reaches the device."""
+    D = st.ELMState(64)
+    bad = np.zeros(64, np.int32)
+    bad[7] = 6
+    with pytest.raises(RuntimeError):
+        D["snl"] = bad
+    bad[7] = -1
+    with pytest.raises(RuntimeError):
+        D["snl"] = bad
+    D["snl"] = np.full(64, 5, np.int32)
+    assert (D["snl"] == 5).all()
+    D.close()
+
+
+def test_fp32_state_variant_error_envelope():
+    """BASELINE config 5's second half (libelmk_f32.so: every fp64 state field stored as fp32, fp64 arithmetic, fused step) is
+    a REPORT, not a parity claim: its outputs cannot be within 1e-12 of the reference's.  What is asserted is the documented
+    envelope of one step against the oracle on the same inputs: inputs are held to fp32 rounding, the
+    median relative difference of the outputs stays below 1e-6, nine values in ten below 1e-5, and the int fields that do not
+    depend on a tolerance-terminated iteration are exact.  (The tails are NOT small - a leaf-temperature iteration that takes
+    one trip more or fewer moves a flux by per cent - which is why this build is never the product.)"""
+    from elmkernels_amd import _lib as L
+
+    n = 20000
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier="A", seed=77)
+    D = st.ELMState(n, lib_path=L.F32_LIB_PATH)
+    assert D.lib.elmk_state_real_bytes() == 4
+    pft, optics = synth.load_params()
+    D.set_pft(pft); D.set_snicar(optics); D.set_soilcolor(soil["albsat"], soil["albdry"])
+    D.set_land(**synth.TEST_LAND); D.set_scalars(**scal)
+    for k, v in cols.items():
+        D.upload(k, v, col0=0)
+    # storage really is fp32: what comes back is the input rounded to nearest fp32, and the state takes half the bytes
+    back = D["t_soisno"]
+    assert np.array_equal(back, cols["t_soisno"].astype(np.float32).astype(np.float64))
+    D64 = st.ELMState(n)
+    assert D.device_bytes < 0.75 * D64.device_bytes
+    D64.close()
+    S = H.oracle_state(cols, scal, soil)
+    st.timestep7_fused(D, DT)
+    S.timestep7(DT)
+    rels = []
+    for name in ("t_veg", "t_grnd", "h2ocan", "btran", "qflx_evap_tot", "eflx_sh_tot", "eflx_lh_tot", "cgrnd", "t_ref2m", "q_ref2m", "albd", "albi",
+                 "fabd", "sabg", "sabv", "fsa", "fsr", "qg", "thm", "tssbef", "rootr", "eff_porosity", "fwet", "fdry", "ulrad", "dlrad"):
+        a, b = D[name].astype(np.float64).ravel(), S[name].astype(np.float64).ravel()
+        scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-30)
+        r = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, np.abs(a - b) / scale)
+        rels.append(r[np.isfinite(r)])
+    r = np.concatenate(rels)
+    med, p90 = float(np.median(r)), float(np.percentile(r, 90))
+    print(f"fp32 state vs oracle after one step: median {med:.2e}  p90 {p90:.2e}  p99 {np.percentile(r, 99):.2e}  max {r.max():.2e}")
+    assert med < 1e-6 and p90 < 1e-5, (med, p90)
+    assert np.array_equal(D["snl"], S["snl"]) and np.array_equal(D["nrad"], S["nrad"])
+    flags, _ = D.error_summary()
+    assert (flags & 0x7FF) == 0
+    D.close()
+
+
+def test_reference_outputs_on_device():
+    """HIP directly against outputs of the REFERENCE ITSELF on branch-mix columns (tests/golden/ref_branch_mix.npz, recorded in
+    the build container from oracle/_ref by tests/refgolden.py): init_timestep, frac_wet, canopy_hydrology,
+    surface_radiation, canopy_temperature, bareground_fluxes, SNICAR's products, the whole soil_temperature solve,
+    surface_fluxes and the conservation diagnostics.  The inputs of every stage are the oracle chain's state (re-synchronised
+    before the stage; its hash must be the recorded one), the expected outputs are the reference's: bit for bit."""
+    from tests import _parity_mode
+    from tests import refgolden as G
+
+    if not _parity_mode.BITWISE_VALID:
+        pytest.skip("another host libm: the oracle chain is not the one the fixture was recorded on")
+    fx = G.load()
+    (cols, scal, soil), S = G.start_state()
+    D = H.device_state(cols, scal, soil)
+    dev = {"init_timestep": lambda: st.kokkos_init_timestep(D), "frac_wet": lambda: st.kokkos_frac_wet(D),
+           "albedo_snicar": lambda: st.kokkos_albedo_snicar(D), "canopy_hydrology": lambda: st.kokkos_canopy_hydrology(D, G.DT),
+           "surface_radiation": lambda: st.kokkos_surface_radiation(D), "canopy_temperature": lambda: st.kokkos_canopy_temperature(D),
+           "bareground_fluxes": lambda: st.kokkos_bareground_fluxes(D), "canopy_fluxes": lambda: st.kokkos_canopy_fluxes(D, G.DT),
+           "soil_temperature": lambda: st.kokkos_soil_temperature(D, G.DT), "snow_hydrology": lambda: st.kokkos_snow_hydrology(D, G.DT),
+           "surface_fluxes": lambda: st.kokkos_surface_fluxes(D, G.DT)}
+    checked = 0
+    for stage in G.STAGES:
+        assert str(fx[f"hash/{stage}"]) == G.state_hash(S), f"{stage}: the oracle chain is not the recorded one"
+        for k, v in S.fields.items():  # the stage starts from the recorded inputs
+            if k != "err_flags":
+                D[k] = v
+        day = S["coszen"] > 0
+        dev[stage]()
+        G.run_oracle(S, stage)
+        for k in [k for k in fx.files if k.startswith(f"out/{stage}/")]:
+            got, exp = D[k.split("/")[2]], fx[k]
+            if exp.dtype.kind == "f":
+                same = (got.view(np.uint64) == exp.view(np.uint64)) | (np.isnan(got) & np.isnan(exp))
+            else:
+                same = got == exp
+            assert same.all(), f"{k}: {int((~same).sum())} values differ from the reference's"
+            checked += 1
+        if stage == "albedo_snicar":
+            assert np.array_equal(D["albsnd"][day], fx["out/snicar/albsnd"][day]) and np.array_equal(D["albsni"][day], fx["out/snicar/albsni"][day])
+            for name, f, band, alb in (("flx_absdv", "flx_absd_snw", 0, "albsnd"), ("flx_absdn", "flx_absd_snw", 1, "albsnd"),
+                                       ("flx_absiv", "flx_absi_snw", 0, "albsni"), ("flx_absin", "flx_absi_snw", 1, "albsni")):
+                exp = fx[f"out/snicar/{f}"][:, :, band] * (1.0 - fx[f"out/snicar/{alb}"][:, band : band + 1])
+                assert np.array_equal(D[name][day], exp[day]), name
+            checked += 6
+    for k, v in S.fields.items():
+        if k != "err_flags":
+            D[k] = v
+    mms, per_col = st.kokkos_evaluate_conservation(D, G.DT, per_column=True)
+    assert np.array_equal(per_col, fx["out/evaluate_conservation/diag"], equal_nan=True)
+    assert checked >= 130
+    D.close()
 
 
 def _fixture_device_state(module, rows, pft, optics, **scalars):

@@ -35,6 +35,22 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
 
 
+def test_fp32_state_build_has_the_same_abi():
+    """libelmk_f32.so (BASELINE config 5's report-only variant: fp64 fields stored as fp32) is the same ABI, symbol for symbol,
+    says what it stores, and refuses to compute without a device like the product."""
+    lib = _lib.load()
+    lib32 = _lib.load(_lib.F32_LIB_PATH)
+    for name in _header_symbols():
+        assert hasattr(lib32, name), f"libelmk_f32.so lacks {name}"
+    assert lib.elmk_state_real_bytes() == 8 and lib32.elmk_state_real_bytes() == 4
+    assert lib32.elmk_num_fields() == lib.elmk_num_fields()
+    import torch
+
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        assert lib32.elmk_create(16, 0, ctypes.byref(h)) == -2 and not h.value
+
+
 def test_no_cpu_fallback_without_device():
     """Without a HIP device the product refuses to create a context (it must never compute on the CPU)."""
     lib = _lib.load()
@@ -187,3 +203,11 @@ def test_solar_geometry_matches_the_reference_sources():
     for a, b, what in zip(out["mine"], out["ref"], ("average_cosz", "daylength", "max_daylength")):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), what
     assert (out["ref"][0] > 0).mean() > 0.3 and (out["ref"][0] == 0).mean() > 0.2  # day and night both sampled
+
+
+def test_parity_bar_is_announced():
+    """The bar the device-vs-oracle tests hold is decided once per session (tests/conftest.py) and printed in the report header;
+    it must be one of the two documented ones."""
+    from tests import _parity_mode as M
+
+    assert isinstance(M.BITWISE_VALID, bool) and M.REASON

@@ -197,3 +197,37 @@ def test_canopy_fluxes_derived_rho_close():
     assert np.abs(nit_g - nit_d).max() <= 1  # a last-bit change can move the convergence test by one iteration
     for name in fout:
         assert np.max(F.rel_err(got_g[name], got_d[name], floor=1e-12)) < 1e-6, name
+
+
+def test_oracle_matches_the_committed_reference_outputs():
+    """tests/golden/ref_branch_mix.npz: what the REFERENCE ITSELF (oracle/_ref, recorded in the build container by
+    tests/refgolden.py) returns on 1 024 branch-mix columns for every stage of advance() its headers can run.  The oracle walks
+    the same sequence here - also where /root/reference does not exist - and must reproduce every recorded field bit for bit."""
+    from tests import _parity_mode
+    from tests import refgolden as G
+
+    fx = G.load()
+    _, S = G.start_state()
+    checked = 0
+    for stage in G.STAGES:
+        if str(fx[f"hash/{stage}"]) != G.state_hash(S):
+            assert not _parity_mode.BITWISE_VALID, f"{stage}: the oracle chain left the recorded one on a host with the recorded libm"
+            pytest.skip("another host libm: the oracle chain is not the one the fixture was recorded on")
+        before = S.clone() if stage == "albedo_snicar" else None
+        G.run_oracle(S, stage)
+        keys = [k for k in fx.files if k.startswith(f"out/{stage}/")]
+        for k in keys:
+            got, exp = S[k.split("/")[2]], fx[k]
+            assert ((got == exp) | (np.isnan(got.astype(float)) & np.isnan(exp.astype(float)))).all(), k
+            checked += 1
+        if stage == "albedo_snicar":
+            day = before["coszen"] > 0
+            assert np.array_equal(S["albsnd"][day], fx["out/snicar/albsnd"][day]) and np.array_equal(S["albsni"][day], fx["out/snicar/albsni"][day])
+            for name, f, band, alb in (("flx_absdv", "flx_absd_snw", 0, "albsnd"), ("flx_absdn", "flx_absd_snw", 1, "albsnd"),
+                                       ("flx_absiv", "flx_absi_snw", 0, "albsni"), ("flx_absin", "flx_absi_snw", 1, "albsni")):
+                exp = fx[f"out/snicar/{f}"][:, :, band] * (1.0 - fx[f"out/snicar/{alb}"][:, band : band + 1])
+                assert np.array_equal(S[name][day], exp[day]), name
+            checked += 6
+    assert str(fx["hash/evaluate_conservation"]) == G.state_hash(S)
+    assert np.array_equal(S.evaluate_conservation(G.DT), fx["out/evaluate_conservation/diag"], equal_nan=True)
+    assert checked >= 130

@@ -18,6 +18,16 @@ for spec in "A timestep7 tierA" "B timestep7 tierB" "A fused fused_tierA" "B fus
   cp $O/hbm_traffic_pmc_$name.json $R/profiles/${P}_hbm_traffic_pmc_$name.json
   rm -rf $O/pmc_fetch $O/pmc_write
 done
+# 1a. the fp32-state build (BASELINE config 5's report-only variant): traffic of its fused step
+export ELMK_LIBRARY=$R/elmkernels_amd/libelmk_f32.so
+for tier in A B; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 1000000 $tier fused > $O/pmc_fetch_f32_$tier.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 1000000 $tier fused > $O/pmc_write_f32_$tier.log 2>&1
+  python3 $R/tests/tools/make_traffic_json.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic_pmc_fused_f32_tier$tier.json 1000000 $tier | tee $O/hbm_traffic_fused_f32_tier$tier.txt
+  cp $O/hbm_traffic_pmc_fused_f32_tier$tier.json $R/profiles/${P}_hbm_traffic_pmc_fused_f32_tier$tier.json
+  rm -rf $O/pmc_fetch $O/pmc_write
+done
+unset ELMK_LIBRARY
 # 1b. the compute side (SQ counters, one group per pass): VALU busy, VALU lane utilisation, fp64 instruction mix of every kernel
 for tier in A B; do
   rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_lane -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 1000000 $tier timestep7 > $O/pmc_lane_$tier.log 2>&1
@@ -28,7 +38,7 @@ for tier in A B; do
 done
 # 2. the benchmark line (reads the tables written above) and its rocprofv3 kernel statistics
 cd $R
-python3 bench.py > $O/bench_1M.json 2> $O/bench_1M.err
+python3 bench.py --state-f32 > $O/bench_1M.json 2> $O/bench_1M.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-tier --no-north-star > $O/bench_1M_under_rocprof.json 2> $O/kt.log
 cp $O/kt/p_kernel_stats.csv $O/bench_1M_rocprof_kernel_stats.csv

@@ -22,6 +22,7 @@
 #include "elmk_kernels.h"
 #include "elmk_stream.h"
 #include "elmk_albedo_col.h"
+#include "elmk_snicar.h"
 
 #ifndef CF_PROBE
 #define CF_PROBE 0  // 4/5: development timeline probes (tests/tools/cf_timeline.py), never set in the product build
@@ -1666,6 +1667,42 @@ __device__ __forceinline__ void fz_pre_tile(const DevState* __restrict__ S, cons
   }
 }
 
+// k_fz_snicar_pre - ONE kernel with two kinds of workgroups, dealt alternately: the single-layer SNICAR queue (k_alb_snicar<1>'s
+// work: bound by fp64 issue, 0.25 ms on the fixture-tiled state) and k_fz_pre's tiles (bound by HBM, 0.29 ms).  As two kernels,
+// even on two streams, they ran one after the other - each launch fills the machine, and the command processor hands out one
+// kernel's workgroups at a time (step timeline in profiles/r03_tl_fused_split_two_streams_tierA.txt: k_fz_pre beside empty
+// SNICAR queues, k_alb_snicar<1> after it).  Inside one kernel both kinds are resident on every CU at once, so the memory-bound
+// waves fill the issue slots the arithmetic-bound ones leave and the other way round.  Registers and LDS are the maximum of
+// the two bodies (SNICAR's 112 VGPRs).
+__global__ __launch_bounds__(256, 2) void k_fz_snicar_pre(const DevState* __restrict__ S, const uint32_t g_snicar, const uint32_t g_pre)
+{
+  // workgroup b -> (kind, index): alternate while both kinds last, then the longer one's remainder
+  const uint32_t b = blockIdx.x, m = g_snicar < g_pre ? g_snicar : g_pre;
+  bool pre;
+  uint32_t idx;
+  if (b < 2u * m) {
+    pre = (b & 1u) != 0u;
+    idx = b >> 1;
+  } else {
+    pre = g_pre > g_snicar;
+    idx = m + (b - 2u * m);
+  }
+  if (!pre) {
+    snicar_workgroup<1>(S, idx, g_snicar);
+    return;
+  }
+  elmk_math_lds_init<false>();
+  if (S->land.lakpoi) {
+    if (idx == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+    return;
+  }
+  fz_pre_tile(S, (int64_t)idx);
+}
+
+#ifndef FZ_SPLIT
+#define FZ_SPLIT 2  // 2: k_fz_pre's tiles share a kernel with the single-layer SNICAR queue (k_fz_snicar_pre); 1: k_fz_pre beside
+                    // the albedo stage on a side stream; 0: k_fz_stream does that work itself, as in round 2 (1, 0: development A/B)
+#endif
 __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict__ S, double dtime)
 {
   elmk_math_lds_init<false>();
@@ -1673,11 +1710,20 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
   const int64_t ld = S->ld;
   const Land L = S->land;
   const bool inside = c < S->ncols;
+#if !FZ_SPLIT
+  int64_t pos0 = -1;
+  if (!L.lakpoi) {
+    pos0 = cf_queue_position(S, inside ? (int)S->cf_cls[c] : -1);
+    if (inside) S->cf_pos[c] = (int32_t)pos0;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
+  }
+#endif
   ColFwd w;
   canopy_hydrology_col<true>(S, c, ld, L, dtime, w, inside);  // (every thread: the pond solves are pooled per workgroup)
   if (inside) {
     surface_radiation_col<true>(S, c, ld, L, w);
-    canopy_temperature_col<true, true>(S, c, ld, L, w);
+    canopy_temperature_col<true, FZ_SPLIT != 0>(S, c, ld, L, w);
   }
   // bareground_fluxes, streaming stage (k_bg_main): compute_flux's unconditional cgrnd reset and the list of bare columns
   if (!L.lakpoi) {
@@ -1689,7 +1735,7 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
     const bool bare = inside && !L.urbpoi && w.fvn == 0;
     block_classify_append<1>(S->lists, ld, S->counters, LIST_BG, bare ? 0 : -1, (int32_t)c);
     // canopy_fluxes up to the iteration (queue position and root moisture stress: k_fz_pre)
-    if (inside) cf_init_col<true, true>(S, c, ld, L, (int64_t)S->cf_pos[c], w);
+    if (inside) cf_init_col<true, FZ_SPLIT != 0>(S, c, ld, L, (int64_t)S->cf_pos[c], w);
   }
 }
 
@@ -1700,7 +1746,15 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
   switch (stage) {
     case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + FZ_PREP_TILES - 1) / FZ_PREP_TILES), dim3(256), 0, st, S); break;
     case 1:
-      if (n >= 262144) {
+      if (!FZ_SPLIT) {
+        launch_albedo_snicar(S, n, st, side, false);
+      } else if (FZ_SPLIT == 2 && n >= 262144) {
+        // the SNICAR queues of 5..2 layers, then the single-layer queue and k_fz_pre's tiles as ONE kernel, then k_alb_final
+        unsigned gs = 0;
+        launch_albedo_snicar_part(S, n, st, 0, &gs);
+        hipLaunchKernelGGL(k_fz_snicar_pre, dim3(gs + nblk), dim3(256), 0, st, S, gs, nblk);
+        launch_albedo_snicar_part(S, n, st, 1, nullptr);
+      } else if (n >= 262144) {
         // k_fz_pre (memory-bound) beside the albedo stage (fp64-issue-bound) on a side stream; joined before k_fz_stream
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->s[0], side->fork, 0);

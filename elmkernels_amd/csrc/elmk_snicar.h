@@ -276,9 +276,10 @@ __device__ __forceinline__ void snicar_band(const DevState* __restrict__ S, cons
 // snow_albedo_radiation_factor (:673-757) for one pass of one column, from the five band results held by five
 // consecutive lanes (band b at lane g0 + b): VIS is band 0, NIR the flux-weighted sum of bands 1..4 in band order.
 // Every lane of the group computes the same values; the caller lets one of them store.
-template <int NL>
-__device__ __forceinline__ void snicar_combine(const int g0, const int pass, const double mu_not, const int rds_top,
-                                               const double albedo, const double (&fl)[6], SnowOut& out)
+// band_albedo(b) / band_flux(b, i): how this lane reads band b's results (shuffles from the lanes beside it, or LDS)
+template <int NL, class FA, class FF>
+__device__ __forceinline__ void snicar_combine_from(const int pass, const double mu_not, const int rds_top, const FA band_albedo,
+                                                    const FF band_flux, SnowOut& out)
 {
   constexpr int snl_top = 5 - NL;
   // 5-band flux weights (:710-723)
@@ -289,19 +290,19 @@ __device__ __forceinline__ void snicar_combine(const int g0, const int pass, con
   const double flx_wgt[5] = {1.0, w1, w2, w3, w4};
   double alb_nir_sum = 0.0, wgt_sum = 0.0;
   double nir_sum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  out.alb[0] = __shfl(albedo, g0, 64);
+  out.alb[0] = band_albedo(0);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    out.fabs_[i][0] = __shfl(fl[i], g0, 64);  // zero wherever the solver does not write (i < snl_top)
+    out.fabs_[i][0] = band_flux(0, i);  // zero wherever the solver does not write (i < snl_top)
     out.fabs_[i][1] = 0.0;
   }
 #pragma unroll
   for (int b = 1; b < 5; b++) {
-    alb_nir_sum += flx_wgt[b] * __shfl(albedo, g0 + b, 64);
+    alb_nir_sum += flx_wgt[b] * band_albedo(b);
     wgt_sum += flx_wgt[b];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const double f = __shfl(fl[i], g0 + b, 64);
+      const double f = band_flux(b, i);
       if (i >= snl_top) nir_sum[i] += flx_wgt[b] * f;
     }
   }
@@ -319,6 +320,16 @@ __device__ __forceinline__ void snicar_combine(const int g0, const int pass, con
     out.alb[1] *= sza_factor;
     out.fabs_[snl_top][1] -= flx_sza_adjust;
   }
+}
+
+// ... from the five band results held by five consecutive lanes (band b at lane g0 + b)
+template <int NL>
+__device__ __forceinline__ void snicar_combine(const int g0, const int pass, const double mu_not, const int rds_top,
+                                               const double albedo, const double (&fl)[6], SnowOut& out)
+{
+  snicar_combine_from<NL>(
+      pass, mu_not, rds_top, [&](const int b) { return __shfl(albedo, g0 + b, 64); },
+      [&](const int b, const int i) { return __shfl(fl[i], g0 + b, 64); }, out);
 }
 
 // the work of one workgroup of k_alb_snicar<NL>: workgroup `block` of `nblocks` (a kernel that hosts other work beside SNICAR
@@ -367,5 +378,11 @@ __device__ __forceinline__ void snicar_workgroup(const DevState* __restrict__ S,
     if (valid && err) atomicOr(ELMK_GENERIC(&S->err_flags[c]), err);
   }
 }
+
+// Measured and dropped in round 3 (profiles/r03_snicar_band_per_wave_ab.txt): one BAND per wave for the packs of two or more
+// layers (a 320-thread workgroup = 5 bands x 64 columns of one pass, results combined through LDS).  It removes the divergence
+// between the visible lanes, which work through every layer, and the near-infrared lanes, whose layers go dark (trntdr <=
+// trmin, :414) early - VALU lane utilisation of k_alb_snicar<5> is 40 % - but at 188-236 VGPRs only one five-wave workgroup
+// fits a CU, every wave gathers its own copy of the layer inputs and there is a barrier per 64 columns: 1.4-1.6 x slower.
 
 }  // namespace elmk

@@ -293,6 +293,12 @@ __global__ __launch_bounds__(256, 2) void k_alb_snicar(const DevState* __restric
 {
   snicar_workgroup<NL>(S, blockIdx.x, gridDim.x);
 }
+// the queue of NL >= 2 layers
+template <int NL>
+static void launch_snicar_deep(const DevState* S, const unsigned capped, const int64_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_alb_snicar<NL>, dim3(capped), dim3(256), 0, st, S);
+}
 
 // =====================================================================================================
 // stage 3 (coalesced, every column): night defaults (init_timestep), or for a sunlit column ground_albedo,
@@ -377,18 +383,18 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   // costs a few microseconds, so the launches simply follow each other; the fork and join through side streams cost
   // ~35 us of dependency latency per call and only pay when the queues are too short to fill the machine.
   if (n >= 262144) {
-    hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, st, S);
+    launch_snicar_deep<5>(S, capped, n, st);
+    launch_snicar_deep<4>(S, capped, n, st);
+    launch_snicar_deep<3>(S, capped, n, st);
+    launch_snicar_deep<2>(S, capped, n, st);
     hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, st, S);
   } else {
     (void)hipEventRecord(side->fork, st);
     for (int i = 0; i < 4; i++) (void)hipStreamWaitEvent(side->s[i], side->fork, 0);
-    hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);  // longest work on the caller's stream
-    hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, side->s[0], S);
-    hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, side->s[1], S);
-    hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, side->s[2], S);
+    launch_snicar_deep<5>(S, capped, n, st);  // longest work on the caller's stream
+    launch_snicar_deep<4>(S, capped, n, side->s[0]);
+    launch_snicar_deep<3>(S, capped, n, side->s[1]);
+    launch_snicar_deep<2>(S, capped, n, side->s[2]);
     hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, side->s[3], S);
     for (int i = 0; i < 4; i++) {
       (void)hipEventRecord(side->join[i], side->s[i]);
@@ -408,10 +414,10 @@ void launch_albedo_snicar_part(const DevState* S, int64_t n, hipStream_t st, int
   const unsigned capped = want < 4096u ? want : 4096u;
   if (snicar_grid) *snicar_grid = capped;
   if (part == 0) {
-    hipLaunchKernelGGL(k_alb_snicar<5>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<4>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<3>, dim3(capped), block, 0, st, S);
-    hipLaunchKernelGGL(k_alb_snicar<2>, dim3(capped), block, 0, st, S);
+    launch_snicar_deep<5>(S, capped, n, st);
+    launch_snicar_deep<4>(S, capped, n, st);
+    launch_snicar_deep<3>(S, capped, n, st);
+    launch_snicar_deep<2>(S, capped, n, st);
   } else {
     hipLaunchKernelGGL(k_alb_final, dim3((unsigned)((n + 255) / 256)), block, 0, st, S);
   }

@@ -384,5 +384,8 @@ __device__ __forceinline__ void snicar_workgroup(const DevState* __restrict__ S,
 // between the visible lanes, which work through every layer, and the near-infrared lanes, whose layers go dark (trntdr <=
 // trmin, :414) early - VALU lane utilisation of k_alb_snicar<5> is 40 % - but at 188-236 VGPRs only one five-wave workgroup
 // fits a CU, every wave gathers its own copy of the layer inputs and there is a barrier per 64 columns: 1.4-1.6 x slower.
+// A second variant kept the product's occupancy - visible band and near-infrared bands in different waves (32 columns x 2
+// passes of band 0; 8 columns x 2 passes x bands 1..4), no LDS, no barrier: -8 % .. +2 %, because a near-infrared wave still runs
+// as deep as its deepest band-1 lane and there are more of them.  The ten-lane form stays.
 
 }  // namespace elmk

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -830,9 +831,49 @@ int elmk_evaluate_conservation(elmk_ctx* ctx, double dt, double* min_max_sum, do
 // ELMInterface::advance order (elm_kokkos_interface.cc:289-307).  ONE stage table per launch structure drives the plain
 // path, the graph capture and the profiled path, so the three cannot drift apart.
 namespace {
+// roctx ranges named after the labels the reference gives its parallel_for launches (driver/kokkos/*_kokkos.cc:
+// "kokkos_canhydro_fracwet_kernel", "kokkos_albedo_and_snicar", ...), so that a marker trace of this library reads like one of
+// the reference (tracing).  Off unless ELMK_ROCTX=1 is set when the first context is created; the marker
+// library is looked up at run time (no link dependency), and a missing one just leaves the ranges off.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx()
+  {
+    const char* e = getenv("ELMK_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx()
+{
+  static const Roctx r;
+  return r;
+}
+struct RoctxRange {
+  explicit RoctxRange(const char* label)
+  {
+    if (roctx().push) roctx().push(label);
+  }
+  ~RoctxRange()
+  {
+    if (roctx().pop) roctx().pop();
+  }
+};
+const char* const TS7_LABELS[7] = {"kokkos_canhydro_fracwet_kernel", "kokkos_albedo_and_snicar", "kokkos_canopy_hydrology", "kokkos_surface_radiation",
+                                   "kokkos_canopy_temperature",     "kokkos_bareground_fluxes", "kokkos_canopy_fluxes"};
 constexpr int TS7_NSTAGE = 7;
 void launch_stage7(elmk_ctx* ctx, int k, double dt)
 {
+  const RoctxRange range(TS7_LABELS[k < 7 ? k : 6]);
   switch (k) {
     case 0: launch_frac_wet(ctx->d, ctx->ncols, ctx->stream); break;
     case 1: launch_albedo_snicar(ctx->d, ctx->ncols, ctx->stream, &ctx->side); break;
@@ -1019,6 +1060,9 @@ int elmk_profile_steps(elmk_ctx* ctx, int fused, double dt, int nsteps, float* m
 namespace {
 void launch_one_wrapper(elmk_ctx* ctx, int wrapper, double dt)
 {
+  const RoctxRange range(wrapper == ELMK_WRAPPER_SOIL_TEMPERATURE ? "kokkos_soil_temperature"
+                         : wrapper == ELMK_WRAPPER_SNOW_HYDROLOGY ? "kokkos_snow_hydrology"
+                         : wrapper == ELMK_WRAPPER_SURFACE_FLUXES ? "kokkos_surface_fluxes" : "elmk_wrapper");
   if (wrapper <= ELMK_WRAPPER_CANOPY_FLUXES)
     launch_stage7(ctx, wrapper, dt);
   else if (wrapper == ELMK_WRAPPER_SOIL_TEMPERATURE)

@@ -3,7 +3,7 @@
 # bandwidth-bound, and the kernel timelines of one step.  bash tests/tools/pmc_round.sh <tag>  -> gpurun_out/<tag>/
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-T=${1:-pmc_r2}
+T=${1:-pmc_r3}
 O=$R/gpurun_out/$T
 mkdir -p $O
 export PMC_GROUPS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS;GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64"

@@ -1,13 +1,17 @@
 #!/bin/bash
-# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag>  (outputs under gpurun_out/<tag>/,
-# the files to commit are copied to profiles/ with the round prefix)
+# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag> [pmc|bench|rest|all]
+# (outputs under gpurun_out/<tag>/; tests/tools/collect_profiles.sh copies the files to commit into profiles/ with the round
+# prefix.  One gpurun call is limited to 20 minutes, so a round is three calls - pmc, then bench, then rest - with a
+# collect_profiles.sh after the first: the benchmark reads the PMC tables from profiles/.)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 T=${1:-prof}
+STAGE=${2:-all}
 P=${PROFILE_TAG:-r03}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [ $STAGE = pmc ] || [ $STAGE = all ]; then
 # 1. HBM traffic per kernel (PMC, one counter per pass): the per-wrapper step and the fused step on both synthetic tiers,
 #    and the soil-column solve
 for spec in "A timestep7 tierA" "B timestep7 tierB" "A fused fused_tierA" "B fused fused_tierB" "B soil soil_tierB"; do
@@ -36,6 +40,8 @@ for tier in A B; do
   cp $O/compute_pmc_tier$tier.json $R/profiles/${P}_compute_pmc_tier$tier.json
   rm -rf $O/pmc_lane $O/pmc_f64
 done
+fi
+if [ $STAGE = bench ] || [ $STAGE = all ]; then
 # 2. the benchmark line (reads the tables written above) and its rocprofv3 kernel statistics
 cd $R
 python3 bench.py --state-f32 > $O/bench_1M.json 2> $O/bench_1M.err
@@ -46,6 +52,9 @@ rm -rf $O/kt
 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --fused --no-cpu-baseline --no-other-tier --no-north-star > $O/bench_1M_fused_under_rocprof.json 2> $O/ktf.log
 cp $O/kt/p_kernel_stats.csv $O/bench_1M_fused_rocprof_kernel_stats.csv
 rm -rf $O/kt
+for f in bench_1M.json bench_1M_rocprof_kernel_stats.csv bench_1M_fused_rocprof_kernel_stats.csv; do cp $O/$f $R/profiles/${P}_$f; done
+fi
+if [ $STAGE = rest ] || [ $STAGE = all ]; then
 cd $R
 # 3. BASELINE config 3: the soil-column vertical solve
 python3 bench.py --workload soil_temperature --cols 10000000 --steps 5 --warmup 2 --tier B > $O/bench_soil_10M.json 2> $O/bench_soil_10M.err
@@ -53,5 +62,6 @@ python3 bench.py --workload soil_temperature --no-cpu-baseline --tier B > $O/ben
 # 4. the rest of advance() and the multi-rank rehearsal (two ranks sharing this one GPU, gloo for the barrier)
 python3 tests/tools/advance_times.py 1000000 B 5 > $O/advance_times_1M.txt 2>&1
 python3 bench.py --gpus 2 --cols 500000 --no-cpu-baseline > $O/bench_2ranks_on_1gpu.json 2> $O/bench_2ranks.err
-for f in bench_1M.json bench_1M_rocprof_kernel_stats.csv bench_1M_fused_rocprof_kernel_stats.csv bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json; do cp $O/$f $R/profiles/${P}_$f; done
+for f in bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json; do cp $O/$f $R/profiles/${P}_$f; done
+fi
 echo done

@@ -652,9 +652,6 @@ __device__ __forceinline__ int64_t cf_queue_position(const DevState* __restrict_
 // earlier bodies of the same pass produced come through ColFwd).  pos: the column's queue position (-1: not vegetated).
 // given: bit 0 / 1 / 2 = forc_rho / forc_po2 / forc_pco2 come from S->cf_given (elmk_canopy_fluxes_given) instead of being
 // derived from the forcing as the wrapper does (canopy_fluxes_kokkos.cc:47-49)
-#ifndef CF_ROOT_AHEAD
-#define CF_ROOT_AHEAD 1  // 0: every level loads its inputs when it needs them (development A/B)
-#endif
 // soil_moist_stress (soil_moist_stress_impl.hh:62-133) of one vegetated column: effective porosity, liquid volume and root
 // moisture stress of the 15 soil levels -> eff_porosity, rootr, btran (state and queue record).  liq0: the liquid water of the
 // top soil level as canopy_fluxes sees it (in the fused step's early kernel: what canopy_hydrology is about to leave there).
@@ -666,56 +663,32 @@ __device__ __forceinline__ void cf_root_stress_col(const DevState* __restrict__ 
   const double tc_stress = P[P_tc_stress], smpso = P[P_smpso], smpsc = P[P_smpsc];
   double btran = 0.0;  // btran0
   double rootr[NLEVGRND];
-  // The eight inputs of a level are loaded one level AHEAD of their use (CF_ROOT_AHEAD): the level's own work ends in a branch
-  // around a pow, and a load the source places after a branch is not issued before it - without the look-ahead every level
-  // waits for its own loads, fifteen trips to HBM one after the other.
-  struct RootLev {
-    double watsat, dz, ice, liq, tsoi, sucsat, bsw, rootfr;
-  };
-#define CF_ROOT_LOAD(v, i)                                                                                                   \
-  {                                                                                                                          \
-    v.watsat = LV(watsat, i);                                                                                                \
-    v.dz = LV(dz, NLEVSNO + (i));                                                                                            \
-    v.ice = LV(h2osoi_ice, NLEVSNO + (i));                                                                                   \
-    v.liq = ((i) == 0) ? liq0 : (double)LV(h2osoi_liq, NLEVSNO + (i));                                                       \
-    v.tsoi = LV(t_soisno, NLEVSNO + (i));                                                                                    \
-    v.sucsat = LV(sucsat, i);                                                                                                \
-    v.bsw = LV(bsw, i);                                                                                                      \
-    v.rootfr = LV(rootfr, i);                                                                                                \
-  }
-  RootLev nxt;
-  CF_ROOT_LOAD(nxt, 0)
+  // (Loading a level's inputs one level ahead of their use was measured: no gain - the kernel is bound by bandwidth, not by
+  // latency - and it made the three loads of the unfrozen branch unconditional: +230 bytes per column.  They stay conditional.)
 #pragma unroll
   for (int i = 0; i < NLEVGRND; i++) {
-    const RootLev v = nxt;
-#if CF_ROOT_AHEAD
-    if (i + 1 < NLEVGRND) CF_ROOT_LOAD(nxt, i + 1)
-#endif
-    const double watsat = v.watsat;
-    const double dzi = v.dz;
+    const double watsat = LV(watsat, i);
+    const double dzi = LV(dz, NLEVSNO + i);
     // calc_effective_soilporosity (soil_moist_stress_impl.hh:62-73)
-    const double vol_ice = dmin(watsat, (v.ice / (DENICE * dzi)));
+    const double vol_ice = dmin(watsat, (LV(h2osoi_ice, NLEVSNO + i) / (DENICE * dzi)));
     const double eff_por = watsat - vol_ice;
     LV(eff_porosity, i) = eff_por;
     // calc_volumetric_h2oliq (:77-86)
-    const double liqvol = dmin(eff_por, (v.liq / (dzi * DENH2O)));
+    const double liq = (i == 0) ? liq0 : (double)LV(h2osoi_liq, NLEVSNO + i);
+    const double liqvol = dmin(eff_por, (liq / (dzi * DENH2O)));
     // calc_root_moist_stress (:89-133), perchroot == perchroot_alt == 0
-    const double tsoi = v.tsoi;
+    const double tsoi = LV(t_soisno, NLEVSNO + i);
     if (liqvol <= 0.0 || tsoi <= TFRZ + tc_stress) {
       rootr[i] = 0.0;
     } else {
       const double s_node = dmax(liqvol / eff_por, 0.01);
-      double smp_node = -v.sucsat * elmk_pow(s_node, (-v.bsw));
+      double smp_node = -LV(sucsat, i) * elmk_pow(s_node, (-LV(bsw, i)));
       smp_node = dmax(smpsc, smp_node);
       const double rresis = dmin((eff_por / watsat) * (smp_node - smpsc) / (smpso - smpsc), 1.0);
-      rootr[i] = v.rootfr * rresis;
+      rootr[i] = LV(rootfr, i) * rresis;
       btran += dmax(rootr[i], 0.0);
     }
-#if !CF_ROOT_AHEAD
-    if (i + 1 < NLEVGRND) CF_ROOT_LOAD(nxt, i + 1)
-#endif
   }
-#undef CF_ROOT_LOAD
 #pragma unroll
   for (int i = 0; i < NLEVGRND; i++) {
     double q = rootr[i];

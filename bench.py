@@ -477,7 +477,9 @@ def spawn_ranks(ngpus, argv, timeout_s=None, poll_s=0.2):
             continue
         sys.stderr.write(err_text)
         out0.seek(0)
-        sys.stdout.write(out0.read().decode())
+        for line in out0.read().decode(errors="replace").splitlines():
+            # stdout carries the ONE JSON line; anything else a library printed there (gloo's connection banner) goes to stderr
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
         sys.stdout.flush()
         return rc
     return 1

@@ -44,7 +44,8 @@ def _load(path):
 
 class _Lib:
     def __init__(self):
-        p = os.path.join(HERE, "libelmoracle.so")
+        # ELMO_LIBRARY: another build of the same sources (tests/test_oracle_sanitizers.py loads an ASan / UBSan build)
+        p = os.environ.get("ELMO_LIBRARY") or os.path.join(HERE, "libelmoracle.so")
         if not os.path.exists(p):
             build(ref=False)
         self.lib = C.CDLL(p)

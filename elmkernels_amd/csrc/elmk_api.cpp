@@ -544,11 +544,24 @@ int elmk_snapshot_fields(elmk_ctx* ctx, const int* fields, int nfields)
 int elmk_restore_fields(elmk_ctx* ctx)
 {
   if (int rc = enter(ctx)) return rc;
+  // plain streaming kernels (hipMemcpyAsync device-to-device goes through the SDMA engines here, ~80 GB/s), up to
+  // COPY_JOBS_MAX fields per launch: a small field's copy is all launch latency
+  CopyJobs J;
+  J.n = 0;
+  int64_t words = 0;
   for (size_t i = 0; i < ctx->snap_fields.size(); i++) {
     const int f = ctx->snap_fields[i];
     const size_t bytes = (size_t)g_fields[f].nlev * (size_t)ctx->ld * store_size(g_fields[f].dtype);
-    // a plain streaming kernel: hipMemcpyAsync device-to-device goes through the SDMA engines here (~80 GB/s)
-    launch_copy((const double*)ctx->snap_bufs[i], (double*)ctx->fptr[f], (int64_t)(bytes / 8), ctx->stream);
+    words += (int64_t)(bytes / 8);
+    J.src[J.n] = (const double*)ctx->snap_bufs[i];
+    J.dst[J.n] = (double*)ctx->fptr[f];
+    J.end[J.n] = words;
+    J.n++;
+    if (J.n == COPY_JOBS_MAX || i + 1 == ctx->snap_fields.size()) {
+      launch_copy_multi(J, ctx->stream);
+      J.n = 0;
+      words = 0;
+    }
   }
   HIPCHK(hipGetLastError());
   return ELMK_OK;
@@ -853,19 +866,19 @@ struct Roctx {
     }
   }
 };
-const Roctx& roctx()
+const Roctx* roctx()
 {
   static const Roctx r;
-  return r;
+  return &r;
 }
 struct RoctxRange {
   explicit RoctxRange(const char* label)
   {
-    if (roctx().push) roctx().push(label);
+    if (roctx()->push) roctx()->push(label);
   }
   ~RoctxRange()
   {
-    if (roctx().pop) roctx().pop();
+    if (roctx()->pop) roctx()->pop();
   }
 };
 const char* const TS7_LABELS[7] = {"kokkos_canhydro_fracwet_kernel", "kokkos_albedo_and_snicar", "kokkos_canopy_hydrology", "kokkos_surface_radiation",

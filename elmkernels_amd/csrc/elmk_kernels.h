@@ -66,6 +66,15 @@ void launch_tile(void* field, int dtype, int nlev, int64_t ld, int64_t ncols, in
                  int field_id, int mode, double amp, hipStream_t st);
 void launch_flag_reduce(const uint32_t* flags, int64_t n, uint32_t* or_out, long long* first_bad, hipStream_t st);
 void launch_copy(const double* src, double* dst, int64_t n, hipStream_t st, int shape = 0);
+// up to COPY_JOBS_MAX device-to-device copies of 8-byte words in one launch; end[j] = words of jobs 0..j together
+constexpr int COPY_JOBS_MAX = 16;
+struct CopyJobs {
+  const double* src[COPY_JOBS_MAX];
+  double* dst[COPY_JOBS_MAX];
+  int64_t end[COPY_JOBS_MAX];
+  int n;
+};
+void launch_copy_multi(const CopyJobs& J, hipStream_t st);
 void launch_math_eval(int fn, const double* x, const double* y, double* out, int64_t n, hipStream_t st);
 
 }  // namespace elmk

@@ -197,6 +197,24 @@ __global__ __launch_bounds__(256) void k_copy(const double* __restrict__ src, do
   if (i < n) dst[i] = src[i];
 }
 
+// several such copies as ONE launch (elmk_restore_fields: a step of the benchmark restores four 8 MB fields, and four
+// launches of 15 us each - latency, not bytes - were 2.6 % of the step)
+__global__ __launch_bounds__(256) void k_copy_multi(const CopyJobs J)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= J.end[J.n - 1]) return;
+  int j = 0;
+  while (i >= J.end[j]) j++;  // (n <= COPY_JOBS_MAX: a handful of scalar compares)
+  const int64_t k = i - (j ? J.end[j - 1] : 0);
+  J.dst[j][k] = J.src[j][k];
+}
+
+void launch_copy_multi(const CopyJobs& J, hipStream_t st)
+{
+  if (J.n <= 0 || J.end[J.n - 1] <= 0) return;
+  hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)((J.end[J.n - 1] + 255) / 256)), dim3(256), 0, st, J);
+}
+
 // The same copy in other access shapes (elmk_copy_bandwidth_shape): what bounds a streaming kernel on this chip is how many
 // bytes a CU keeps in flight, and that is (bytes per load) x (independent loads per wave) x (resident waves).
 //   shape 1: 16 bytes per lane, one load per thread          (the float4 copy the 6.29 TB/s figure was measured with)

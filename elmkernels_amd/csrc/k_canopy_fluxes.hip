@@ -1701,6 +1701,9 @@ __global__ __launch_bounds__(256, 2) void k_fz_snicar_pre(const DevState* __rest
   fz_pre_tile(S, (int64_t)idx);
 }
 
+#ifndef FZ_SNICAR_GRID_BY_TILES
+#define FZ_SNICAR_GRID_BY_TILES 1  // 0: k_alb_snicar<1>'s own grid for the SNICAR part of k_fz_snicar_pre (development A/B)
+#endif
 #ifndef FZ_SPLIT
 #define FZ_SPLIT 2  // 2: k_fz_pre's tiles share a kernel with the single-layer SNICAR queue (k_fz_snicar_pre); 1: k_fz_pre beside
                     // the albedo stage on a side stream; 0: k_fz_stream does that work itself, as in round 2 (1, 0: development A/B)
@@ -1754,6 +1757,10 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
         // the SNICAR queues of 5..2 layers, then the single-layer queue and k_fz_pre's tiles as ONE kernel, then k_alb_final
         unsigned gs = 0;
         launch_albedo_snicar_part(S, n, st, 0, &gs);
+        // as many SNICAR workgroups as tiles (each walks the queue with that stride: two or three entries per wave), so that the
+        // two kinds alternate for the whole length of the kernel; with k_alb_snicar<1>'s grid of 4 096 long-lived workgroups
+        // the SNICAR part filled the machine first at 10 M columns and the tiles ran behind it
+        if (FZ_SNICAR_GRID_BY_TILES && gs < nblk) gs = nblk;
         hipLaunchKernelGGL(k_fz_snicar_pre, dim3(gs + nblk), dim3(256), 0, st, S, gs, nblk);
         launch_albedo_snicar_part(S, n, st, 1, nullptr);
       } else if (n >= 262144) {

@@ -226,7 +226,7 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   if (hip_fail(ctx, hipMalloc((void**)&ctx->d, sizeof(DevState)), "hipMalloc(params)")) return fail(ELMK_E_NOMEM);
   const size_t wk_bytes = align_up((size_t)WK_N * (size_t)ctx->ld * 8, 256);
   const size_t list_bytes = align_up((size_t)NLISTS * (size_t)ctx->ld * 4, 256);
-  const size_t cnt_bytes = align_up((size_t)(2 * NLISTS + CF_NCLS + 2) * CPAD * 4, 256);  // (+ the canopy queue's tail and grant counters)
+  const size_t cnt_bytes = align_up((size_t)(2 * NLISTS + CF_NCLS) * CPAD * 4, 256);
   const size_t hint_bytes = align_up((size_t)ctx->ld * 4, 256);
   // canopy_fluxes queue records (k_canopy_fluxes.hip), by queue position
   const int64_t cf_nblk = (ncols + 255) / 256 > 0 ? (ncols + 255) / 256 : 1;
@@ -918,8 +918,9 @@ int run_graph(elmk_ctx* ctx, GraphSlot& g, stage_fn fn, int nstage, double dt)
 {
   if (!g.exec || g.dt != dt || g.stream != ctx->stream) {
     if (g.exec) {
-      // (dt or the stream changed: the old executable may still be running its last launch)
-      if (g.stream) HIPCHK(hipStreamSynchronize(g.stream));
+      // dt or the stream changed: the old executable may still be running its last launch.  (Best effort: a caller that
+      // destroyed the old stream has synchronised it itself, and the error of waiting on it is not this call's.)
+      if (g.stream && hipStreamSynchronize(g.stream) != hipSuccess) (void)hipGetLastError();
       (void)hipGraphExecDestroy(g.exec);
       g.exec = nullptr;
     }

@@ -1626,9 +1626,6 @@ __global__ __launch_bounds__(256) void k_fz_prep(const DevState* __restrict__ S)
 // k_fz_stream used to move.  What lies between this kernel and k_fz_stream in the reference's call order touches none of it
 // with one exception: fraction_h2osfc folds a vanishing pond (h2osfc <= 1e-8) into the top soil layer's liquid
 // (canopy_hydrology_impl.hh:334-337), which calc_volumetric_h2oliq then reads - the same sum is formed here for that level.
-#ifndef FZ_PRE_WGS_PER_CU
-#define FZ_PRE_WGS_PER_CU 0  // > 0: a persistent grid of that many workgroups per CU walks the tiles (leaves room for the albedo stage)
-#endif
 __device__ __forceinline__ void fz_pre_tile(const DevState* __restrict__ S, const int64_t tile);
 __global__ __launch_bounds__(256) void k_fz_pre(const DevState* __restrict__ S)
 {
@@ -1637,10 +1634,7 @@ __global__ __launch_bounds__(256) void k_fz_pre(const DevState* __restrict__ S)
     if (blockIdx.x == 0 && threadIdx.x == 0) ELMK_LIST_COUNT(S, LIST_CF_QUEUE) = 0u;
     return;
   }
-  for (int64_t tile = blockIdx.x; tile < S->cf_nblk; tile += gridDim.x) {
-    fz_pre_tile(S, tile);
-    __syncthreads();  // (cf_queue_position's LDS counters are reused by the next tile)
-  }
+  fz_pre_tile(S, (int64_t)blockIdx.x);
 }
 __device__ __forceinline__ void fz_pre_tile(const DevState* __restrict__ S, const int64_t tile)
 {
@@ -1767,8 +1761,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
         // k_fz_pre (memory-bound) beside the albedo stage (fp64-issue-bound) on a side stream; joined before k_fz_stream
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
-        hipLaunchKernelGGL(k_fz_pre, dim3(FZ_PRE_WGS_PER_CU > 0 && nblk > 256u * FZ_PRE_WGS_PER_CU ? 256u * FZ_PRE_WGS_PER_CU : nblk), dim3(256), 0,
-                           side->s[0], S);
+        hipLaunchKernelGGL(k_fz_pre, dim3(nblk), dim3(256), 0, side->s[0], S);
         (void)hipEventRecord(side->join[0], side->s[0]);
         launch_albedo_snicar(S, n, st, side, false);
         (void)hipStreamWaitEvent(st, side->join[0], 0);

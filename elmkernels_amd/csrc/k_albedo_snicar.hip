@@ -268,7 +268,11 @@ __device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const
 // stage 1 (coalesced, every column): canopy_layer_lai, soil albedo of the sunlit columns, and the classification of
 // the sunlit snow-covered columns by their number of snow layers (lists LIST_ALB_1..5)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_alb_classify(const DevState* __restrict__ S)
+#ifndef ALB_CLASSIFY_THREADS
+#define ALB_CLASSIFY_THREADS 1024  // one atomic per workgroup and non-empty queue: with 256-thread workgroups the 3 907 atomics on
+                                   // ONE counter (the fixture-tiled tier fills a single queue) were the kernel's whole time (57 us)
+#endif
+__global__ __launch_bounds__(ALB_CLASSIFY_THREADS) void k_alb_classify(const DevState* __restrict__ S)
 {
   const Land L = S->land;
   // (stage 1 evaluates exp on deep-lake columns only - the ice fraction of soil_albedo: no table copy for the other land units)
@@ -376,7 +380,8 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   // stage 2 is grid-stride over a device-side count: 24 columns per workgroup
   const unsigned want = (unsigned)((n + 23) / 24);
   const unsigned capped = want < 4096u ? want : 4096u;
-  if (classify) hipLaunchKernelGGL(k_alb_classify, dim3(full), block, 0, st, S);
+  if (classify)
+    hipLaunchKernelGGL(k_alb_classify, dim3((unsigned)((n + ALB_CLASSIFY_THREADS - 1) / ALB_CLASSIFY_THREADS)), dim3(ALB_CLASSIFY_THREADS), 0, st, S);
   // The five layer-count queues are independent.  (One persistent launch draining all five lists through a chunk counter
   // was measured 30 % slower: every wave then pays the deepest list's register footprint, and the five unrolled bodies
   // compete for the instruction cache.)  With many columns every non-empty queue fills the GPU by itself and an empty one

@@ -170,7 +170,7 @@ constexpr int CPAD = 32;
 #define ELMK_LIST_COUNT(S, k) ((S)->counters[(k)*CPAD])
 #define ELMK_LIST_HEAD(S, k) ((S)->counters[(NLISTS + (k)) * CPAD])
 
-// Workgroup-aggregated classification append: every thread of the (256-thread) workgroup calls this with its class
+// Workgroup-aggregated classification append: every thread of the workgroup (any size) calls this with its class
 // cls in [0, NCLS) or -1; column c goes to list first_list + cls.  One global atomic per class per workgroup;
 // order inside a list follows (workgroup arrival, wave, lane).  All threads of the workgroup must call it.
 template <int NCLS>

@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __re
 //   active only where frac_veg_nosno == 0; everywhere else just cgrnd/cgrnds/cgrndl = 0
 // =====================================================================================================
 // stage 1 (every column, streaming): compute_flux's unconditional cgrnd reset (:97-102) and the queue of bare columns
-__global__ __launch_bounds__(256) void k_bg_main(const DevState* __restrict__ S)
+// (1024-thread workgroups: one global atomic per workgroup on the bare-ground list's counter, and same-address atomics retire
+//  one after the other at ~14 ns each - with 256-thread workgroups they were most of this kernel's time on a mixed tile,
+//  profiles/r03_classify_atomics_ab.txt)
+#ifndef BG_MAIN_THREADS
+#define BG_MAIN_THREADS 1024
+#endif
+__global__ __launch_bounds__(BG_MAIN_THREADS) void k_bg_main(const DevState* __restrict__ S)
 {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const Land L = S->land;
@@ -213,7 +219,7 @@ void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int 
   if (n <= 0) return;
   const unsigned full = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_bg_reset, dim3(1), dim3(64), 0, st, S);
-  hipLaunchKernelGGL(k_bg_main, dim3(full), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_bg_main, dim3((unsigned)((n + BG_MAIN_THREADS - 1) / BG_MAIN_THREADS)), dim3(BG_MAIN_THREADS), 0, st, S);
   hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, given);
 }
 

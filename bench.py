@@ -96,11 +96,11 @@ def _timed_loop(fn, budget_s, min_steps=3, max_steps=100000):
 def cpu_baseline(host_state, budget_s=12.0, workload="timestep7"):
     """The CPU path beside the GPU numbers, on a bounded sample of the same workload (the whole host-generated base block,
     24 064 columns; every timing covers >= 1 M column-steps so OpenMP fork/join noise stays small):
-      * kind "port": the oracle (plain-C restatement of the reference physics, OpenMP over columns like Kokkos-OpenMP);
-      * "reference_headers": the reference's OWN physics headers (oracle/_ref/libelmref.so, compiled in the build
-        container) under `#pragma omp parallel for schedule(static)` - the execution shape of
-        Kokkos::parallel_for(RangePolicy<OpenMP>) - for the five wrappers whose headers build without netcdf, with the
-        port timed on the same five beside it."""
+      * kind "reference": the seven wrappers run by the reference's OWN physics headers (oracle/_ref/libelmref.so +
+        libelmref_canopy.so, compiled in the build container) under `#pragma omp parallel for` over columns - the execution
+        shape of Kokkos::parallel_for(RangePolicy<OpenMP>);
+      * "port" (beside it; the only figure for the soil-temperature workload or when oracle/_ref is absent): the oracle
+        (plain-C restatement of the reference physics, OpenMP over columns)."""
     from tests import helpers as H
 
     cols, scal, soil = host_state
@@ -135,10 +135,38 @@ def cpu_baseline(host_state, budget_s=12.0, workload="timestep7"):
     }
     if workload != "timestep7" or not O.have_ref():
         return out
-    # the five wrappers the reference's headers cover, in advance() order, reference and port each on its own copy of the
-    # same start state, passes back to back (the state is not put back between passes: nothing but the wrappers is timed)
     R = O.Reference()
     rthreads = int(R.R.elmref_max_threads()) if hasattr(R.R, "elmref_max_threads") else 1
+    if O.have_ref_canopy():
+        # The whole step by the reference's OWN functions (oracle/_ref/libelmref.so + libelmref_canopy.so: the reference's
+        # physics headers compiled in the build container, OpenMP over columns - the execution shape of
+        # Kokkos::parallel_for(RangePolicy<OpenMP>)): this is the baseline; the port's figure stays beside it.
+        Sr = H.oracle_state(sub, scal, soil)
+
+        def ref_step():
+            Sr["t_veg"][:] = tveg
+            for k, v in hg.items():
+                Sr[k][:] = v
+            R.frac_wet(Sr)
+            Sr.albedo_snicar_ref()
+            R.canopy_hydrology(Sr, 1800.0)
+            R.surface_radiation(Sr)
+            R.canopy_temperature(Sr)
+            R.bareground_fluxes(Sr)
+            Sr.canopy_fluxes_ref(1800.0)
+
+        ref_step()
+        rs, re_ = _timed_loop(ref_step, budget_s, min_steps)
+        port = dict(out)
+        out = {
+            "value": n * rs / re_, "unit": "gridcell-timesteps/s", "cores": rthreads, "kind": "reference",
+            "sample": f"{n} columns x {rs} timesteps of the same tier, all seven wrappers by the reference's own physics headers "
+                      f"(oracle/_ref/libelmref.so + libelmref_canopy.so, g++ -O2 -fopenmp, omp parallel for over columns), {re_:.1f} s",
+            "port": port,
+        }
+        return out
+    # (an older oracle/_ref without the canopy library) the five wrappers the reference's headers cover, in advance() order,
+    # reference and port each on its own copy of the same start state, passes back to back
     S.timestep7(1800.0)  # a post-step state: every field the five read has been produced once
     Sr, Sp = S.clone(), S.clone()
 

@@ -29,8 +29,8 @@
 // out of bounds (vol_ice[i+1] is used); combine_layers' shift loop reads element -1 of the level arrays when the pack has
 // five layers (0.0 is used); snow_aging's float -> int conversion of a non-finite index (x86-64's INT_MIN is used).
 // Parity: bit for bit against the oracle's restatement, which is itself pinned bit for bit by the reference's own
-// snow_hydrology_impl.hh for every function but snow_aging and the two aerosol bookkeeping functions (those three: parity
-// unpinned, checked structurally - oracle/elmo_physics_g.c).
+// snow_hydrology.h for every function (snow_aging and its tables included) but the two aerosol bookkeeping functions (those
+// two: parity unpinned, checked structurally - oracle/elmo_physics_g.c).
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 

@@ -238,8 +238,8 @@ int elmk_soil_temperature(elmk_ctx *ctx, double dt);
  * Updates snl and the snow mesh (dz, zsoi, zisoi, t_soisno, h2osoi_ice/liq of the snow levels and of the top soil level),
  * snw_rds, the aerosol masses mss_* and concentrations cnc_*, h2osno, snow_depth, frac_sno(_eff), int_snow, qflx_snow_melt,
  * qflx_top_soil, qflx_sl_top_soil, qflx_snow2topsoi, mflx_*, qflx_rootsoi.  The reference has no fixture for this path; the
- * checker behind the parity tests is pinned bit for bit by the reference's own snow_hydrology_impl.hh for every function
- * but snow_aging and the two aerosol bookkeeping functions (those: parity unpinned).  See ELMK_WARN_SNOW_* for the two
+ * checker behind the parity tests is pinned bit for bit by the reference's own snow_hydrology.h for every function
+ * but the two aerosol bookkeeping functions (those: parity unpinned).  See ELMK_WARN_SNOW_* for the two
  * places where the reference's own result is undefined. */
 int elmk_snow_hydrology(elmk_ctx *ctx, double dt);
 /* kokkos_surface_fluxes(S, dt) (surface_fluxes_kokkos.cc:5-107): flux corrections for the new ground temperature,

@@ -14,11 +14,12 @@
  *
  * Pinning (see tests/test_oracle_golden.py, tests/test_oracle_vs_ref.py):
  *   - all seven reference fixture pairs test/data/<Module>_{IN,OUT}.txt (committed as tests/golden/*.npz);
- *   - the reference's own headers compiled as oracle/_ref/libelmref.so for every physics header that
- *     builds without netcdf (canopy_hydrology, surface_radiation, canopy_temperature,
- *     bareground_fluxes, snow_snicar, friction_velocity, soil_moist_stress, qsat, atm_physics).
- *   canopy_fluxes / photosynthesis / surface_albedo pull in netcdf.h through pft_data.h and are
- *   unbuildable here; they are pinned by CanopyFluxes_{IN,OUT}.txt and SurfaceAlbedo_{IN,OUT}.txt alone.
+ *   - the reference's own headers compiled under oracle/_ref/ (oracle/Makefile, four libraries) and run bit for bit against
+ *     the restatement: all seven wrappers of the hot path - canopy_hydrology, surface_radiation, canopy_temperature,
+ *     bareground_fluxes (libelmref.so) and, since round 3, surface_albedo + snow_snicar and canopy_fluxes + photosynthesis
+ *     (libelmref_canopy.so; pft_data.h reaches netcdf.h only through the file readers, which ref_harness_canopy.cc skips by
+ *     read_input.hh's own include guard - no stand-in for netcdf) - plus soil temperature, surface fluxes, init_timestep,
+ *     the initialisation functions, and eight of the ten stages of snow hydrology.
  */
 #ifndef ELM_ORACLE_H
 #define ELM_ORACLE_H
@@ -425,6 +426,11 @@ void elmo_sms_calc_root_moist_stress(const double *h2osoi_liqvol, const double *
                                      double smpso, double smpsc, const double *eff_porosity, int altmax_indx,
                                      int altmax_lastyear_indx, double *rootr, double *btran);
 
+/* photosynthesis() alone over n independent inputs (elmo_driver.c; same interface as elmref_photosynthesis) */
+void elmo_photosynthesis_batch(int64_t n, const elmo_pft_psn *table, const int *vtype, const int *nrad, const double *in,
+                               double *out, unsigned *err);
+/* test infrastructure: branch counters of the photosynthesis root find (elmo_physics_b.c) */
+void elmo_psn_counters(unsigned long long *out4, int reset);
 unsigned elmo_psn_photosynthesis(const elmo_pft_psn *psnveg, int nrad, double forc_pbot, double t_veg, double t10,
                                  double esat_tv, double eair, double oair, double cair, double rb, double btran,
                                  double dayl_factor, double thm, const double *tlai_z, double vcmaxcint,

@@ -696,3 +696,22 @@ void elmo_timestep7(elmo_state *S, double dt)
   elmo_bareground_fluxes(S);
   elmo_canopy_fluxes(S, dt);
 }
+
+/* photosynthesis() alone, one call per element - the unit stability_iteration calls twice per trip (test infrastructure:
+ * the same interface as elmref_photosynthesis of ref_harness_canopy.cc, which runs the reference's own function).
+ * in[n][15]: tlai_z, par_z, lai_z, forc_pbot, t_veg, t10, esat_tv, eair, oair, cair, rb, btran, dayl_factor, thm, vcmaxcint;
+ * out[n][2]: ci_z (in/out: untouched at night), rs; err[n]: the ELMO_ERR_PSN_* bits the call raised. */
+void elmo_photosynthesis_batch(int64_t n, const elmo_pft_psn *table, const int *vtype, const int *nrad, const double *in,
+                               double *out, unsigned *err)
+{
+  for (int64_t i = 0; i < n; i++) {
+    const double *x = in + i * 15;
+    double tlai_z[1] = {x[0]}, par_z[1] = {x[1]}, lai_z[1] = {x[2]};
+    double ci_z[1] = {out[i * 2]};
+    double rs = out[i * 2 + 1];
+    err[i] = elmo_psn_photosynthesis(&table[vtype[i]], nrad[i], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], x[11], x[12],
+                                     x[13], tlai_z, x[14], par_z, lai_z, ci_z, &rs);
+    out[i * 2] = ci_z[0];
+    out[i * 2 + 1] = rs;
+  }
+}

@@ -226,6 +226,19 @@ static void psn_brent(double *x, double x1, double x2, double f1, double f2, dou
   *x = b;
 }
 
+/* Branch counters of the root find (test infrastructure: the tests that pin this file against the reference's own
+ * photosynthesis() use them to show that their inputs reach Brent's method, the itmax fall-back and the C4 forms).
+ * [0] hybrid calls, [1] calls that entered brent, [2] calls that left through the itmax fall-back, [3] C4 calls. */
+static unsigned long long psn_counts[4];
+void elmo_psn_counters(unsigned long long *out, int reset)
+{
+  for (int i = 0; i < 4; i++) {
+    if (out) out[i] = psn_counts[i];
+    if (reset) psn_counts[i] = 0ull;
+  }
+}
+#define PSN_COUNT(i) _Pragma("omp atomic") psn_counts[i] += 1ull
+
 /* :517-620 hybrid */
 static void psn_hybrid(double *x0, psn_ctx *k)
 {
@@ -234,6 +247,8 @@ static void psn_hybrid(double *x0, psn_ctx *k)
   const int itmax = 40;
   double x1, f0, f1, x, dx, tol, minx, minf;
 
+  PSN_COUNT(0);
+  if (!k->c3flag) PSN_COUNT(3);
   psn_ci_func(*x0, &f0, k);
   if (f0 == 0.0) return;
   minx = *x0;
@@ -271,11 +286,13 @@ static void psn_hybrid(double *x0, psn_ctx *k)
       break;
     }
     if (f1 * f0 < 0.0) {
+      PSN_COUNT(1);
       psn_brent(&x, *x0, x1, f0, f1, tol, k);
       *x0 = x;
       break;
     }
     if (iter > itmax) {
+      PSN_COUNT(2);
       psn_ci_func(minx, &f1, k);
       break;
     }

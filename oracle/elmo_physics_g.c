@@ -6,17 +6,18 @@
  * src/physics/aerosol_physics_impl.hh (:10-107) and src/physics/transpiration_impl.hh (:15-28), one function per
  * reference function.
  *
- * Pinning.  The reference has no fixture for this path, and snow_hydrology.h itself is unbuildable here
- * (snow_hydrology.h:5 -> snicar_data.h:6 -> read_input.hh -> netcdf.h).  The file that holds the function bodies,
- * snow_hydrology_impl.hh, does build when it is included directly (oracle/ref_harness_snow.cc says how: two declarations of
- * the reference's own names, no stand-in for netcdf or for any reference code), so snow_water, aerosol_phase_change,
- * transpiration, snow_compaction, combine_layers (+ combine), divide_layers and prune_snow_layers are run against these
- * restatements BIT FOR BIT, one wrapper stage at a time on identical inputs, over chained model steps in which packs are
- * built, split, merged and pruned (tests/test_oracle_vs_ref.py::test_snow_hydrology_stages_bitwise_vs_reference; columns
- * that take one of the reference's two out-of-bounds reads, (A) and (B) below, are left out - its result there is
- * undefined).  PARITY UNPINNED remain: snow_aging (its table type SnwRdsTable lives in snicar_data.h -> netcdf) and the two
- * whole-array aerosol functions compute_aerosol_deposition / update_aerosol_mass_and_concen (they only dispatch through
- * Kokkos, aerosol_physics_impl.hh:59, :106); those are checked structurally (tests/test_snow_hydrology_oracle.py).
+ * Pinning.  The reference has no fixture for this path.  snow_hydrology.h reaches netcdf.h only through the file readers
+ * (snow_hydrology.h:5 -> snicar_data.h:6 -> read_input.hh -> read_netcdf.hh), which no function here calls; with
+ * read_input.hh skipped through its own include guard the header builds as it lies (oracle/ref_harness_snow.cc says exactly
+ * how: one macro, one declaration of a reference name, no stand-in for netcdf or for any reference code), so snow_water,
+ * aerosol_phase_change, transpiration, snow_compaction, combine_layers (+ combine), divide_layers, prune_snow_layers and
+ * snow_aging (with the reference's own SnwRdsTable) are run against these restatements BIT FOR BIT, one wrapper stage at a
+ * time on identical inputs, over chained model steps in which packs are built, split, merged, pruned and aged
+ * (tests/test_oracle_vs_ref.py::test_snow_hydrology_stages_bitwise_vs_reference; columns that take one of the reference's two
+ * out-of-bounds reads, (A) and (B) below, are left out - its result there is undefined).  PARITY UNPINNED remain the two
+ * whole-array aerosol functions compute_aerosol_deposition / update_aerosol_mass_and_concen: their only body is a lambda
+ * handed to the Kokkos dispatch (aerosol_physics_impl.hh:59, :106), which cannot be instantiated without Kokkos; those are
+ * checked structurally (tests/test_snow_hydrology_oracle.py).
  *
  * Where the reference's result is not defined, the choice made here (and in the HIP kernels, include/elmk.h):
  *   (A) snow_water reads vol_ice[i+i] (:388, meant i+1) from a five-element stack array.  i = 0, 1, 2 are in bounds and

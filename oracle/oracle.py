@@ -120,6 +120,12 @@ class _Lib:
         self.ref_soil = _load(os.path.join(HERE, "_ref", "libelmref_soil.so"))
         if self.ref_soil is not None:
             self.ref_soil.elmref_soil_temperature.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 3
+        # canopy_fluxes.h / photosynthesis.h / surface_albedo.h of the reference (ref_harness_canopy.cc says how they build here)
+        self.ref_canopy = _load(os.path.join(HERE, "_ref", "libelmref_canopy.so"))
+        if self.ref_canopy is not None:
+            self.ref_canopy.elmref_canopy_fluxes.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 3
+            self.ref_canopy.elmref_albedo_snicar.argtypes = [C.c_void_p] * 3
+            self.ref_canopy.elmref_photosynthesis.argtypes = [C.c_int64] + [C.c_void_p] * 6
 
 
 _LIB = None
@@ -291,7 +297,7 @@ class OracleState:
 
     SNOW_STAGES = ("snow_water", "aerosol_deposition", "aerosol_phase_change", "transpiration", "snow_compaction",
                    "combine_layers", "divide_layers", "prune_snow_layers", "aerosol_mass_and_concen", "snow_aging")
-    SNOW_STAGES_REF = (0, 2, 3, 4, 5, 6, 7)  # the stages the reference's own functions can run here (ref_harness_snow.cc)
+    SNOW_STAGES_REF = (0, 2, 3, 4, 5, 6, 7, 9)  # the stages the reference's own functions can run here (ref_harness_snow.cc)
 
     def snow_hydrology_stage(self, dt, stage, ref=False, skip=None):
         """One stage of the wrapper over all columns; ref=True: the reference's own function (columns with skip != 0 untouched).
@@ -311,6 +317,19 @@ class OracleState:
         out = dict(lhs=np.zeros((n, 21, 5)), rhs=np.zeros((n, 21)), hs=np.zeros((n, 4)))
         self._L.ref_soil.elmref_soil_temperature(self.ptr, float(dt), *[out[k].ctypes.data for k in ("lhs", "rhs", "hs")])
         return out
+
+    def canopy_fluxes_ref(self, dt, rho=None, po2=None, pco2=None):
+        """kokkos_canopy_fluxes by the reference's own initialize_flux / stability_iteration (photosynthesis inside) /
+        compute_flux (ref_harness_canopy.cc); a column in which the reference threw gets bit 31 of err_flags."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (rho, po2, pco2)]
+        self._L.ref_canopy.elmref_canopy_fluxes(self.ptr, float(dt), *[None if a is None else a.ctypes.data for a in arrs])
+
+    def albedo_snicar_ref(self):
+        """kokkos_albedo_snicar by the reference's own surface_albedo / snow_snicar functions -> (fabd_sun, fabd_sha)."""
+        sun = np.zeros((self.ncols, 2))
+        sha = np.zeros((self.ncols, 2))
+        self._L.ref_canopy.elmref_albedo_snicar(self.ptr, sun.ctypes.data, sha.ctypes.data)
+        return sun, sha
 
     def set_init_params(self, organic_max, roota_par, rootb_par):
         """organic_max of the parameter file (initialize_elm_kokkos.cc:312) and PFTData::roota_par / rootb_par [25]."""
@@ -384,6 +403,17 @@ def set_pft_tables(psn, alb, z0mr, displar, pft):
         alb[:, j] = np.asarray(pft[name], dtype=np.float64).reshape(-1)[:25]
     z0mr[:] = np.asarray(pft["z0mr"]).reshape(-1)[:25]
     displar[:] = np.asarray(pft["displar"]).reshape(-1)[:25]
+
+
+def psn_counters(reset=False):
+    """Branch counters of the restatement's photosynthesis root find: dict(hybrid, brent, itmax, c4)."""
+    out = (C.c_ulonglong * 4)()
+    lib().lib.elmo_psn_counters(out, 1 if reset else 0)
+    return dict(zip(("hybrid", "brent", "itmax", "c4"), [int(v) for v in out]))
+
+
+def have_ref_canopy():
+    return lib().ref_canopy is not None
 
 
 def have_ref():

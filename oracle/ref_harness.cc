@@ -10,8 +10,8 @@
 //   bareground_fluxes.h (+friction_velocity.h)  snow_snicar.h  soil_moist_stress.h  atm_physics.h
 //   soil_thermal_properties.h  pentadiagonal_solver.h  phase_change.h  surface_fluxes.h  conserved_quantity_evaluators.h
 //   init_topography.h  init_snow_state.h  soil_texture_hydraulic_model.h  init_soil_state.h
-// Not covered (unbuildable here: pft_data.h -> read_input.hh -> read_netcdf.hh -> netcdf.h):
-//   canopy_fluxes.h  photosynthesis.h  surface_albedo.h
+// Not in this file: canopy_fluxes.h, photosynthesis.h, surface_albedo.h (pft_data.h -> read_input.hh -> read_netcdf.hh ->
+//   netcdf.h) - ref_harness_canopy.cc runs them (it skips the readers through read_input.hh's own include guard).
 // The loops below follow the argument wiring of driver/kokkos/*_kokkos.cc (cited per function).
 
 #include "array.hh"
@@ -244,8 +244,8 @@ void elmref_snicar(elmo_state* S, double* flx_absd_snw_out, double* flx_absi_snw
     double* flx_absi = flx_absi_snw_out + (size_t)c * 12;
     std::memset(flx_absd, 0, 12 * sizeof(double));
     std::memset(flx_absi, 0, 12 * sizeof(double));
-    // surface_albedo::init_timestep's aerosol wiring (surface_albedo_impl.hh:141-150) cannot be called
-    // (header needs netcdf); it is a plain copy, reproduced here as harness input preparation
+    // surface_albedo::init_timestep's aerosol wiring (surface_albedo_impl.hh:141-150) is not called in this file (the whole
+    // albedo wrapper by the reference's functions: ref_harness_canopy.cc); it is a plain copy, reproduced here as input preparation
     for (int i = 0; i < 5; i++) {
       mss_[i * 8 + 0] = S->cnc_bcphi[c * 5 + i];
       mss_[i * 8 + 1] = S->cnc_bcpho[c * 5 + i];

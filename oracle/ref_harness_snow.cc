@@ -1,59 +1,72 @@
-// ref_harness_snow.cc - the REFERENCE's own snow-hydrology functions (src/physics/snow_hydrology_impl.hh, transpiration.h),
+// ref_harness_snow.cc - the REFERENCE's own snow-hydrology functions (src/physics/snow_hydrology.h, transpiration.h),
 // included from where they lie under /root/reference at build time (nothing is copied), run one wrapper stage at a time
-// behind the oracle's state container.  Part of oracle/_ref/libelmref.so (oracle/Makefile, build container only).
+// behind the oracle's state container.  Built into oracle/_ref/libelmref_snow.so (oracle/Makefile, build container only).
 //
 // TEST INFRASTRUCTURE ONLY - see elm_oracle.h.
 //
-// Why this is a separate translation unit: snow_hydrology.h itself cannot be included here (snow_hydrology.h:5 ->
-// snicar_data.h:6 -> read_input.hh -> read_netcdf.hh -> netcdf.h, which the image lacks), but the file that holds the
-// function BODIES, snow_hydrology_impl.hh, needs only what is included below plus two NAMES that snow_hydrology.h would
-// have declared before it:
-//   * the class template name SnwRdsTable (snicar_data.h:75) - it appears in the parameter list of snow_aging, which this
-//     harness never instantiates (snow_aging therefore stays "parity unpinned");
-//   * the prototype of ELM::snow::combine (snow_hydrology.h:134-141), which divide_layers calls before the body at
-//     snow_hydrology_impl.hh:1305 is seen.
-// Both are declarations of the reference's own entities - no body, no stand-in for netcdf or for any reference code - so
-// every instruction executed below is the reference's.
+// How it builds without netcdf.  snow_hydrology.h:5 includes snicar_data.h for the class template SnwRdsTable (the three
+// snow-aging tables, snicar_data.h:74-84); snicar_data.h:6 also includes read_input.hh (the file readers) -> read_netcdf.hh ->
+// netcdf.h, which the image lacks.  No function below reads a file.  read_input.hh carries a classic include guard
+// (read_input.hh:1, ELM_UTILS_READ_INPUT_HH_): with that macro defined the reference's own header skips itself, and nothing
+// is put in its place - no netcdf.h, no reader, no body of any kind.  snicar_data_impl.hh:173 then needs one NAME that
+// read_input.hh would have declared, ELM::IO::read_netcdf (read_input.hh:237-245), inside a function template this file never
+// instantiates; it is declared below as the reference declares it, without a body.  Every instruction executed below is the
+// reference's, SnwRdsTable included.  (Round 3 first did this with forward declarations of SnwRdsTable and of
+// ELM::snow::combine in front of snow_hydrology_impl.hh, which left snow_aging out; including the header itself needs neither.)
 //
 // The stage numbers are those of elmo_snow_hydrology_stage (elm_oracle.h): the reference runs 0 snow_water,
-// 2 aerosol_phase_change, 3 transpiration, 4 snow_compaction, 5 combine_layers, 6 divide_layers, 7 prune_snow_layers with
-// the argument wiring of driver/kokkos/snow_hydrology_kokkos.cc:32-160.  Stages 1 and 8 (compute_aerosol_deposition,
-// update_aerosol_mass_and_concen: whole-array functions that only dispatch through Kokkos, aerosol_physics_impl.hh:59,:106)
-// and 9 (snow_aging) have no reference run here.
+// 2 aerosol_phase_change, 3 transpiration, 4 snow_compaction, 5 combine_layers, 6 divide_layers, 7 prune_snow_layers and
+// 9 snow_aging with the argument wiring of driver/kokkos/snow_hydrology_kokkos.cc:32-186.  Stages 1 and 8
+// (compute_aerosol_deposition, update_aerosol_mass_and_concen, aerosol_physics_impl.hh:33-110) have no reference run: they are
+// whole-array functions whose only body is a lambda handed to the three-argument apply_parallel_for, which exists under Kokkos
+// alone (invoke_kernel.hh:41-47 takes two) - they cannot be instantiated here.
 //
 // skip[c] != 0: column c is left untouched.  The tests set it where the restatement reports that the reference reads
 // outside an array (ELMO_WARN_SNOW_WATER_OOB: vol_ice[i+i] with i = 3, snow_hydrology_impl.hh:388; ELMO_WARN_SNOW_COMBINE_OOB:
 // element -1 in the five-layer shift, :871-885): there the reference's result is whatever lies next to the array.
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstddef>
+#include <cstring>
 #include <stdexcept>
+#include <string>
 
 #include "array.hh"
 #include "compile_options.hh"
 #include "elm_constants.h"
 #include "land_data.h"
-#include "snow_snicar.h"
-#include "transpiration.h"
+#include "mpi_types.hh"
 
-namespace ELM {
-template <class ArrayD3>
-struct SnwRdsTable;
-}
-namespace ELM::snow {
-void combine(const double&, const double&, const double&, const double&, double&, double&, double&, double&);
-}
-#include "snow_hydrology_impl.hh"
+#define ELM_UTILS_READ_INPUT_HH_ /* read_input.hh:1-2 - the reference's own include guard (see the header of this file) */
+namespace ELM::IO {
+template <typename T, size_t D>
+void read_netcdf(const Comm_type& comm, const std::string& filename, const std::string& varname, const std::array<GO, D>& start,
+                 const std::array<GO, D>& count, T* arr);
+}  // namespace ELM::IO
+
+#include "snow_hydrology.h"
+#include "transpiration.h"
 
 #include "elm_oracle.h"
 
 using AD1 = ELM::Array<double, 1>;
 using AI1 = ELM::Array<int, 1>;
+using AD3 = ELM::Array<double, 3>;
 #define V(f, n) AD1(n, S->f + (size_t)c * (n))
 
 extern "C" int elmref_snow_hydrology_stage(elmo_state* S, double dt, int stage, const unsigned char* skip)
 {
-  if (!(stage == 0 || (stage >= 2 && stage <= 7))) return -1;
+  if (!(stage == 0 || (stage >= 2 && stage <= 7) || stage == 9)) return -1;
   int threw = 0;
+  // S.snw_rds_table (elm_state.h): the reference's own table type, allocated by its own constructor
+  // (snicar_data_impl.hh:42-47: [idx_T_max + 1][idx_Tgrd_max + 1][idx_rhos_max + 1] = 11 x 31 x 8) and filled from the state
+  ELM::SnwRdsTable<AD3> table;
+  if (stage == 9) {
+    std::memcpy(table.snowage_tau.data(), S->snowage[0], sizeof(double) * ELMO_SNOWAGE_N);
+    std::memcpy(table.snowage_kappa.data(), S->snowage[1], sizeof(double) * ELMO_SNOWAGE_N);
+    std::memcpy(table.snowage_drdt0.data(), S->snowage[2], sizeof(double) * ELMO_SNOWAGE_N);
+  }
   for (int64_t c = 0; c < S->ncols; c++) {
     if (skip && skip[c]) continue;
     try {
@@ -89,9 +102,14 @@ extern "C" int elmref_snow_hydrology_stage(elmo_state* S, double dt, int stage, 
                                    V(mss_bcphi, 5), V(mss_bcpho, 5), V(mss_dst1, 5), V(mss_dst2, 5), V(mss_dst3, 5),
                                    V(mss_dst4, 5), V(dz, 20), V(zsoi, 20), V(zisoi, 21));
           break;
-        default:  // :150-157
+        case 7:  // :150-157
           ELM::snow::prune_snow_layers(S->snl[c], V(h2osoi_ice, 20), V(h2osoi_liq, 20), V(t_soisno, 20), V(dz, 20), V(zsoi, 20),
                                        V(zisoi, 21));
+          break;
+        default:  // :170-186
+          ELM::snow::snow_aging(S->do_capsnow[c], S->snl[c], S->frac_sno[c], dt, S->qflx_snwcp_ice[c], S->qflx_snow_grnd[c],
+                                S->h2osno[c], V(dz, 20), V(h2osoi_liq, 20), V(h2osoi_ice, 20), V(t_soisno, 20),
+                                V(qflx_snofrz_lyr, 5), table, V(snw_rds, 5));
       }
     } catch (const std::exception&) {
       S->err_flags[c] |= 1u << 31;  // the reference threw (divide_layers' radius checks, :1032 ...)

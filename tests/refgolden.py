@@ -24,8 +24,9 @@ N, TIER, SEED, DT = 1024, "B", 4242, 1800.0
 # (stage, how the reference runs it or None, how the oracle runs it)
 STAGES = ("init_timestep", "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
           "bareground_fluxes", "canopy_fluxes", "soil_temperature", "snow_hydrology", "surface_fluxes")
-REF_STAGES = ("init_timestep", "frac_wet", "canopy_hydrology", "surface_radiation", "canopy_temperature", "bareground_fluxes",
-              "soil_temperature", "surface_fluxes")  # + SNICAR inside albedo_snicar, + the conservation diagnostics at the end
+REF_STAGES = ("init_timestep", "frac_wet", "albedo_snicar", "canopy_hydrology", "surface_radiation", "canopy_temperature",
+              "bareground_fluxes", "canopy_fluxes", "soil_temperature", "surface_fluxes")  # + the conservation diagnostics at the end
+# (snow_hydrology: the reference's functions run seven of its ten stages, tests/test_oracle_vs_ref.py; not the whole wrapper)
 
 
 def start_state():
@@ -60,6 +61,7 @@ def run_reference(S, stage):
     {"init_timestep": lambda: S.init_timestep(lib=R.R), "frac_wet": lambda: R.frac_wet(S),
      "canopy_hydrology": lambda: R.canopy_hydrology(S, DT), "surface_radiation": lambda: R.surface_radiation(S),
      "canopy_temperature": lambda: R.canopy_temperature(S), "bareground_fluxes": lambda: R.bareground_fluxes(S),
+     "albedo_snicar": S.albedo_snicar_ref, "canopy_fluxes": lambda: S.canopy_fluxes_ref(DT),
      "soil_temperature": lambda: S.soil_temperature_ref(DT), "surface_fluxes": lambda: S.surface_fluxes(DT, lib=R.R)}[stage]()
 
 
@@ -91,8 +93,8 @@ def generate():
             for k, v in changed_fields(S, T).items():
                 data[f"out/{stage}/{k}"] = v
         if stage == "albedo_snicar":
-            # the SNICAR products of both passes from the reference (the albedo wrapper itself needs netcdf): albsnd / albsni and
-            # the per-layer absorbed-flux factors, on the state in which the oracle's wrapper left albsoi / albsod
+            # the SNICAR products of both passes on their own as well (the wrapper drops the per-layer absorbed-flux factors
+            # flx_absd_snw / flx_absi_snw after folding them into flx_abs*): on the state in which the wrapper left albsoi / albsod
             T = S.clone()
             T.albedo_snicar()
             T["albsnd"][:] = -1.0

@@ -500,6 +500,42 @@ def test_fp32_state_variant_error_envelope():
     D.close()
 
 
+def test_hot_path_on_device_against_the_reference_library():
+    """HIP against the REFERENCE ITSELF with no restatement in between: the prebuilt oracle/_ref/libelmref.so and
+    libelmref_canopy.so (the reference's own physics headers, compiled in the build container; the binaries travel to the GPU
+    box, /root/reference does not) run the seven wrappers of the step on the host - the oracle's state object is only the
+    container of the arrays - and the device runs elmk_timestep7 / elmk_timestep7_fused on the same start state: three chained
+    model steps, 40 000 branch-mix columns with all 24 leafed plant types (C3 and C4), then a soybean land unit: every field
+    bit for bit."""
+    from oracle import oracle as O
+    from tests import _parity_mode
+
+    if not (O.have_ref() and O.have_ref_canopy()):
+        pytest.skip("oracle/_ref libraries not built")
+    if not _parity_mode.BITWISE_VALID:
+        pytest.skip("another host libm than the one the device math restates")
+    R = O.Reference()
+    for n, seed, land in ((40000, 71, None), (8000, 72, dict(ltype=1, ctype=1, vtype=23, urbpoi=0, lakpoi=0))):
+        ft = st.field_table()
+        cols, scal, soil = synth.make_state(ft, n, tier="B", seed=seed)
+        cols["vtype"] = np.random.default_rng(seed).integers(1, 25, n).astype(np.int32)
+        B = H.oracle_state(cols, scal, soil, land)
+        D = H.device_state(cols, scal, soil, land)
+        for step in range(3):
+            (st.timestep7_fused if step == 1 else st.timestep7)(D, DT)
+            R.frac_wet(B)
+            B.albedo_snicar_ref()
+            R.canopy_hydrology(B, DT)
+            R.surface_radiation(B)
+            R.canopy_temperature(B)
+            R.bareground_fluxes(B)
+            B.canopy_fluxes_ref(DT)
+            assert not (B["err_flags"] >> 31).any(), "the reference threw"
+            _check(D, B, f"HIP vs the reference's own functions, land {land}, step {step}", bitwise=True)
+            assert (D["err_flags"] & 0x7FF == 0).all()
+        D.close()
+
+
 def test_reference_outputs_on_device():
     """HIP directly against outputs of the REFERENCE ITSELF on branch-mix columns (tests/golden/ref_branch_mix.npz, recorded in
     the build container from oracle/_ref by tests/refgolden.py): init_timestep, frac_wet, canopy_hydrology,

@@ -56,7 +56,8 @@ def test_five_wrappers_bit_exact_vs_reference(states):
     assert not _same(A, B)
     A.canopy_hydrology(1800.0); R.canopy_hydrology(B, 1800.0)
     assert not _same(A, B)
-    # albedo products come from the oracle on both sides (surface_albedo.h is unbuildable from the reference)
+    # albedo products come from the oracle on both sides here (the albedo wrapper by the reference's own functions, and all
+    # seven wrappers chained by the reference alone: tests/test_oracle_vs_ref_canopy.py)
     A.albedo_snicar()
     for k in A.fields:
         B.fields[k][...] = A.fields[k]
@@ -364,11 +365,11 @@ def test_soil_temperature_whole_wrapper_bitwise(soil_states):
 
 
 # ---- kokkos_snow_hydrology, one wrapper stage at a time, by the reference's own functions (oracle/ref_harness_snow.cc:
-# snow_water, aerosol_phase_change, transpiration, snow_compaction, combine_layers, divide_layers, prune_snow_layers).  Columns
-# in which the reference reads outside an array (the restatement raises a warning bit exactly there) are left out: its
-# result there is whatever lies next to the array.  Not run by the reference: the two whole-array aerosol functions (Kokkos
-# dispatch only) and snow_aging (needs SnwRdsTable -> netcdf): those three stay "parity unpinned".
-WARN_WATER, WARN_COMBINE, ERR_DIVIDE = 1 << 12, 1 << 13, 1 << 14
+# snow_water, aerosol_phase_change, transpiration, snow_compaction, combine_layers, divide_layers, prune_snow_layers, snow_aging
+# with the reference's own SnwRdsTable).  Columns in which the reference reads outside an array (the restatement raises a
+# warning bit exactly there) are left out: its result there is whatever lies next to the array.  Not run by the reference: the
+# two whole-array aerosol functions (their only body is a lambda for the Kokkos dispatch): those two stay "parity unpinned".
+WARN_WATER, WARN_COMBINE, ERR_DIVIDE, ERR_AGE = 1 << 12, 1 << 13, 1 << 14, 1 << 15
 
 
 @pytest.mark.skipif(O.lib().ref_snow is None, reason="oracle/_ref/libelmref_snow.so not built here")
@@ -376,6 +377,7 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
     DT = 1800.0
     ft = H.field_table_from_oracle()
     seen_snl_change = {5: 0, 6: 0}
+    aged = 0
     compared = {s: 0 for s in O.OracleState.SNOW_STAGES_REF}
     skipped = 0
     for seed in (5, 21):
@@ -390,6 +392,7 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
                 R = S.clone() if ref_runs else None
                 before = S["err_flags"].copy()
                 snl_before = S["snl"].copy()
+                R0_rds = S["snw_rds"].copy()
                 S.snow_hydrology_stage(DT, stage)
                 if not ref_runs:
                     continue
@@ -398,8 +401,8 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
                 R["err_flags"][...] = 0
                 threw = R.snow_hydrology_stage(DT, stage, ref=True, skip=skip)
                 ref_threw = (R["err_flags"] >> 31) != 0
-                # the reference throws exactly where the restatement raises the divide_layers radius flag
-                assert threw == int(ref_threw.sum()) and np.array_equal(ref_threw, (raised & ERR_DIVIDE) != 0), (seed, step, stage)
+                # the reference throws exactly where the restatement raises the divide_layers radius flag / snow_aging's dr_fresh flag
+                assert threw == int(ref_threw.sum()) and np.array_equal(ref_threw, (raised & (ERR_DIVIDE | ERR_AGE)) != 0), (seed, step, stage)
                 ok = ~skip & ~ref_threw
                 for k in S.fields:
                     if k == "err_flags":
@@ -411,7 +414,10 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
                 skipped += int(skip.sum())
                 if stage in seen_snl_change:
                     seen_snl_change[stage] += int((S["snl"] != snl_before).sum())
+                if stage == 9:
+                    aged += int((S["snw_rds"] != R0_rds).any(axis=1).sum())
             S.surface_fluxes(DT)
     # the comparison saw what it is meant to see: layers merged and split, and only a small share of columns was left out
     assert seen_snl_change[5] > 200 and seen_snl_change[6] > 200, seen_snl_change
+    assert aged > 8000, aged  # snow_aging grew the grains of the layered packs (table look-ups included)
     assert min(compared.values()) > 40000 and skipped < 0.15 * compared[0], (compared, skipped)  # (five-layer packs: 10 % of tier B)

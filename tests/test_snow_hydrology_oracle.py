@@ -1,6 +1,6 @@
 """kokkos_snow_hydrology in the oracle (oracle/elmo_physics_g.c), structural checks.  The reference has no fixture for this
-path; its own snow functions are run against the restatement bit for bit in tests/test_oracle_vs_ref.py, all but snow_aging and
-the two aerosol bookkeeping functions, which are PARITY UNPINNED and only covered here.  What can be checked without the
+path; its own snow functions are run against the restatement bit for bit in tests/test_oracle_vs_ref.py, all but the two
+aerosol bookkeeping functions, which are PARITY UNPINNED and only covered here.  What can be checked without the
 reference is checked: the layer re-meshing conserves what it must conserve (water, ice, the six
 aerosol masses, enthalpy), it leaves a consistent mesh, it is idempotent on a settled pack, the documented choices for
 the reference's two out-of-bounds reads are flagged exactly when they are taken, and the whole wrapper keeps the column

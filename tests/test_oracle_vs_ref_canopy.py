@@ -209,3 +209,46 @@ def test_seven_wrappers_chained_by_the_reference():
             d = _diff(A, B)
             assert not d, (step, name, d)
     assert (A["t_veg"] != A["forc_tbot"]).any() and (A["snl"] > 0).any()
+
+
+def test_reference_functions_on_the_references_own_fixtures():
+    """The reference's CanopyFluxes and SurfaceAlbedo fixtures (test/data/*_IN.txt, committed as tests/golden/*.npz), driven as
+    test_CanFlux.cc / test_SurfAlb.cc drive them, through the reference's own functions and through the restatement: the same
+    bits in every field - so the 73 comparisons in which the restatement misses CanopyFluxes_OUT.txt at 1e-15
+    (tests/test_oracle_golden.py; BASELINE.md section 2 reports the same count for the compiled reference) are, value for
+    value, the reference's own."""
+    d = F.load("CanopyFluxes")
+    rows = F.select_steps(d, "CanopyFluxes")
+    probe = O.OracleState(1)
+    fin, oin = F.split(d, "in/", rows, probe.nlev)
+    fout, _ = F.split(d, "out/", rows, probe.nlev)
+    beyond = 0
+    for i in range(len(rows)):
+        S = O.OracleState(1)
+        S.load_params()
+        S.set_scalars(**F.TEST_LAND, dayl=float(oin["dayl"][i, 0]), max_dayl=float(oin["max_dayl"][i, 0]))
+        F.fill_state(S, {k: v[i : i + 1] for k, v in fin.items()})
+        S["vtype"][:] = F.TEST_LAND["vtype"]
+        B = S.clone()
+        S.canopy_fluxes_given(F.TEST_DTIME, oin["forc_rho"][i], oin["forc_po2"][i], oin["forc_pco2"][i])
+        B.canopy_fluxes_ref(F.TEST_DTIME, oin["forc_rho"][i], oin["forc_po2"][i], oin["forc_pco2"][i])
+        assert not (B["err_flags"] & REF_THREW).any()
+        dd = _diff(S, B)
+        assert not dd, (i, dd)
+        for name, exp in fout.items():
+            ok = F.almost_equal(B[name].reshape(1, -1).astype(np.float64), exp[i : i + 1]) | np.isnan(exp[i : i + 1])
+            beyond += int((~ok).sum())
+    assert 0 < beyond <= 120, beyond  # the reference itself misses its fixture at 1e-15 in a few dozen values (73 when recorded)
+
+    d = F.load("SurfaceAlbedo")
+    rows = F.select_steps(d, "SurfaceAlbedo")
+    S = O.OracleState(len(rows))
+    S.load_params()
+    S.set_scalars(**F.TEST_LAND)
+    fin, _ = F.split(d, "in/", rows, S.nlev)
+    F.fill_state(S, fin)
+    S["vtype"][:] = F.TEST_LAND["vtype"]
+    B = S.clone()
+    sa = S.albedo_snicar_ex()
+    sb = B.albedo_snicar_ref()
+    assert not _diff(S, B) and np.array_equal(sa[0], sb[0], equal_nan=True) and np.array_equal(sa[1], sb[1], equal_nan=True)

@@ -62,6 +62,8 @@ python3 bench.py --workload soil_temperature --no-cpu-baseline --tier B > $O/ben
 # 4. the rest of advance() and the multi-rank rehearsal (two ranks sharing this one GPU, gloo for the barrier)
 python3 tests/tools/advance_times.py 1000000 B 5 > $O/advance_times_1M.txt 2>&1
 python3 bench.py --gpus 2 --cols 500000 --no-cpu-baseline > $O/bench_2ranks_on_1gpu.json 2> $O/bench_2ranks.err
-for f in bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json; do cp $O/$f $R/profiles/${P}_$f; done
+# 5. the box itself (record what the roofline denominators refer to)
+{ rocminfo | grep -E "Marketing Name|Name: +gfx|Compute Unit|Max Clock Freq|Wavefront Size|Workgroup Max Size:|Size: +[0-9]+\(0x[0-9a-f]+\) KB" | sort | uniq -c | sort -rn | head -40; echo; rocm-smi --showmeminfo vram --showclocks --showproductname 2>/dev/null | grep -v "^$" | head -60; } > $O/device_info.txt 2>&1 || true
+for f in bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json device_info.txt; do cp $O/$f $R/profiles/${P}_$f; done
 fi
 echo done

@@ -252,3 +252,27 @@ def test_reference_functions_on_the_references_own_fixtures():
     sa = S.albedo_snicar_ex()
     sb = B.albedo_snicar_ref()
     assert not _diff(S, B) and np.array_equal(sa[0], sb[0], equal_nan=True) and np.array_equal(sa[1], sb[1], equal_nan=True)
+
+
+def test_reference_throws_where_the_restatement_flags():
+    """A throw site of the albedo wrapper that inputs can reach: a snow grain radius beyond the Mie table
+    (snow_snicar_impl.hh:74-78).  The reference throws in exactly the columns in which the restatement raises
+    ELMO_ERR_SNICAR_RDS, and every other column comes out bit for bit.  (The device raises the same bits as the restatement:
+    tests/test_gpu_parity.py::test_error_flags_match_the_reference_throw_sites.)"""
+    A = _state(4096, 91)
+    bad = np.random.default_rng(5).choice(4096, 400, replace=False)
+    A["snw_rds"][bad] = 5000.0
+    A.frac_wet()
+    B = A.clone()
+    A.albedo_snicar()
+    B.albedo_snicar_ref()
+    threw = (B["err_flags"] & REF_THREW) != 0
+    flagged = (A["err_flags"] & np.uint32(1 << 6)) != 0
+    assert np.array_equal(threw, flagged) and 20 <= int(threw.sum()) < 400  # (only sunlit columns with a snow pack get there)
+    keep = ~threw
+    for k in A.fields:
+        if k == "err_flags":
+            continue
+        a, b = A.fields[k][keep], B.fields[k][keep]
+        eq = (a == b) | (np.isnan(a.astype(float)) & np.isnan(b.astype(float)))
+        assert eq.all(), (k, int((~eq).sum()))

@@ -1738,6 +1738,9 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
   }
 }
 
+#ifndef FZ_BG_OVERLAP
+#define FZ_BG_OVERLAP 1
+#endif
 void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st, const SideStreams* side, int stage)
 {
   if (n <= 0) return;
@@ -1771,11 +1774,27 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
       }
       break;
     case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;
-    case 3: launch_bareground_list(S, n, st); break;
+    case 3:
+      // The bare-ground Monin-Obukhov loop touches bare columns only and the canopy iteration vegetated ones: no field in common.
+      // With FZ_BG_OVERLAP the list kernel goes to a side stream behind k_cf_iterate's launch (case 4): a few hundred workgroups
+      // of long dependent chains that cannot fill the machine on their own (VALU busy 0.31 on the branch-mix tier) run in the
+      // CUs the persistent iteration kernel frees during its tail, instead of in front of it.
+      if (FZ_BG_OVERLAP && n >= 262144) {
+        (void)hipEventRecord(side->fork, st);
+      } else {
+        launch_bareground_list(S, n, st);
+      }
+      break;
     default: {
       const unsigned groups = nblk < 512u ? nblk : 512u;
       hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, 0);
+      if (FZ_BG_OVERLAP && n >= 262144) {
+        (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
+        launch_bareground_list(S, n, side->s[0]);
+        (void)hipEventRecord(side->join[0], side->s[0]);
+      }
       hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt, 0);
+      if (FZ_BG_OVERLAP && n >= 262144) (void)hipStreamWaitEvent(st, side->join[0], 0);
     }
   }
 }

@@ -182,15 +182,19 @@ __device__ __forceinline__ void snow_water(const SnowCol& K, const int do_capsno
 }
 
 // ---- snow_compaction (:553-645) -----------------------------------------------------------------------
-__device__ __forceinline__ void snow_compaction(const DevState* __restrict__ S, const SnowCol& K, const int64_t c, const int snl,
-                                                const int ltype, const double dtime, const double int_snow,
-                                                const double n_melt, const double frac_sno)
+// imelt_r / melt_r: the per-layer inputs the loop reads from the state - imelt and, by land unit, swe_old (soil, crop) or
+// frac_iceold - loaded by the caller beside the pack (a load issued inside the loop is a stall of the one wave a SIMD holds);
+// the loop is unrolled over the five levels so that they stay in registers
+__device__ __forceinline__ void snow_compaction(const SnowCol& K, const int snl, const int ltype, const double dtime,
+                                                const double int_snow, const double n_melt, const double frac_sno,
+                                                const int (&imelt_r)[NLEVSNO], const double (&melt_r)[NLEVSNO])
 {
   const double c2 = 23.e-3, c3 = 2.777e-6, c4 = 0.04, c5 = 2.0, dm = 100.0, eta0 = 9.0e+5;
-  const int64_t ld = S->ld;
   const int top = NLEVSNO - snl;
   double burden = 0.0;
-  for (int i = top; i < NLEVSNO; ++i) {
+#pragma unroll
+  for (int i = 0; i < NLEVSNO; ++i) {
+    if (i < top) continue;
     const double ice = AT(K.ice, i), liq = AT(K.liq, i), dzi = AT(K.dz, i);
     const double wx = (ice + liq);
     const double vd = 1.0 - (ice / DENICE + liq / DENH2O) / (frac_sno * dzi);
@@ -204,9 +208,9 @@ __device__ __forceinline__ void snow_compaction(const DevState* __restrict__ S, 
       if (liq > 0.01 * dzi * frac_sno) ddz1 *= c5;
       const double ddz2 = -(burden + wx / 2.0) * elmk_exp(-0.08 * td - c2 * bi) / eta0;
       double ddz3;
-      if (S->imelt[(int64_t)i * ld + c] == 1) {
+      if (imelt_r[i] == 1) {
         if (ltype == istsoil || ltype == istcrop) {  // subgridflag() == 1
-          const double swe = S->swe_old[(int64_t)i * ld + c];
+          const double swe = melt_r[i];
           ddz3 = dmax(0.0, dmin(1.0, (swe - wx) / wx));
           double wsum = 0.0;
           if ((swe - wx) > 0.0) {
@@ -218,7 +222,7 @@ __device__ __forceinline__ void snow_compaction(const DevState* __restrict__ S, 
           }
           ddz3 = -1.0 / dtime * ddz3;
         } else {
-          const double fio = S->frac_iceold[(int64_t)i * ld + c];
+          const double fio = melt_r[i];
           ddz3 = -1.0 / dtime * dmax(0.0, (fio - fi) / fio);
         }
       } else {
@@ -523,48 +527,66 @@ __device__ __forceinline__ void divide_layers(const SnowCol& K, const double fra
 }
 
 // ---- snow_aging (:50-244) ---------------------------------------------------------------------------------
-__device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const SnowCol& K, const int64_t c, const int do_capsnow,
-                                           const int snl, const double frac_sno, const double dtime, const double qflx_snwcp_ice,
-                                           const double qflx_snow_grnd, const double h2osno, uint32_t& err)
+// Two passes over the five levels, both unrolled (a level above the pack is skipped): the first forms the three table indices
+// of every layer and issues all the table reads together - fifteen gathers in flight instead of three at a time behind
+// each layer's arithmetic, with one wave per SIMD to hide them - the second does each layer's arithmetic as before.  Layers
+// do not depend on each other here (the pass writes snw_rds only and reads its own element of it), so every layer sees
+// exactly the operands it saw in the layer-by-layer form.  snofrz_r: qflx_snofrz_lyr of the five levels, read by the caller.
+__device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const SnowCol& K, const int do_capsnow, const int snl,
+                                           const double frac_sno, const double dtime, const double qflx_snwcp_ice,
+                                           const double qflx_snow_grnd, const double h2osno, const double (&snofrz_r)[NLEVSNO],
+                                           uint32_t& err)
 {
   const double snw_rds_refrz = 1000.0;
   const double C2_liq_Brun89 = 4.22e-13;
-  const int64_t ld = S->ld;
   if (snl > 0) {
-    const int snl_btm = NLEVSNO - 1;
     const int snl_top = NLEVSNO - snl;
-    for (int i = 0; i < snl_top; ++i) AT(K.rds, i) = 0.0;
+#pragma unroll
+    for (int i = 0; i < NLEVSNO; ++i)
+      if (i < snl_top) AT(K.rds, i) = 0.0;
     const gptr<const double> tab = S->snowage;
-    for (int i = snl_top; i <= snl_btm; ++i) {
-      const double liq = AT(K.liq, i), ice = AT(K.ice, i), dzi = AT(K.dz, i), ti = AT(K.t, i);
-      const double h2osno_lyr = liq + ice;
-      double t_snotop, t_snobtm;
-      {
-        const double t_dn = AT(K.t, i + 1), dz_dn = AT(K.dz, i + 1);
-        if (i == snl_top) {
-          t_snotop = ti;
-          t_snobtm = (t_dn * dzi + ti * dz_dn) / (dzi + dz_dn);
-        } else {
-          const double t_up = AT(K.t, i - 1), dz_up = AT(K.dz, i - 1);
-          t_snotop = (t_up * dzi + ti * dz_up) / (dzi + dz_up);
-          t_snobtm = (t_dn * dzi + ti * dz_dn) / (dzi + dz_dn);
+    double bst_tau[NLEVSNO], bst_kappa[NLEVSNO], bst_drdt0[NLEVSNO];
+#pragma unroll
+    for (int i = 0; i < NLEVSNO; ++i) {
+      int k = 0;  // (a level above the pack reads element 0 and does not use it: the reads stay branch-free)
+      if (i >= snl_top) {
+        const double liq = AT(K.liq, i), ice = AT(K.ice, i), dzi = AT(K.dz, i), ti = AT(K.t, i);
+        double t_snotop, t_snobtm;
+        {
+          const double t_dn = AT(K.t, i + 1), dz_dn = AT(K.dz, i + 1);
+          if (i == snl_top) {
+            t_snotop = ti;
+            t_snobtm = (t_dn * dzi + ti * dz_dn) / (dzi + dz_dn);
+          } else {
+            const double t_up = AT(K.t, i > 0 ? i - 1 : 0), dz_up = AT(K.dz, i > 0 ? i - 1 : 0);
+            t_snotop = (t_up * dzi + ti * dz_up) / (dzi + dz_up);
+            t_snobtm = (t_dn * dzi + ti * dz_dn) / (dzi + dz_dn);
+          }
         }
+        const double cdz = frac_sno * dzi;
+        const double dTdz = fabs((t_snotop - t_snobtm) / cdz);
+        double rhos = (liq + ice) / cdz;
+        rhos = dmax(50.0, rhos);
+        int T_idx = round_to_int((ti - 223) / 5);
+        int Tgrd_idx = round_to_int(dTdz / 10);
+        int rhos_idx = round_to_int((rhos - 50) / 50);
+        if (T_idx < 0) T_idx = 0;
+        if (T_idx > 10) T_idx = 10;
+        if (Tgrd_idx < 0) Tgrd_idx = 0;
+        if (Tgrd_idx > 30) Tgrd_idx = 30;
+        if (rhos_idx < 0) rhos_idx = 0;
+        if (rhos_idx > 7) rhos_idx = 7;
+        k = (T_idx * 31 + Tgrd_idx) * 8 + rhos_idx;
       }
-      const double cdz = frac_sno * dzi;
-      const double dTdz = fabs((t_snotop - t_snobtm) / cdz);
-      double rhos = (liq + ice) / cdz;
-      rhos = dmax(50.0, rhos);
-      int T_idx = round_to_int((ti - 223) / 5);
-      int Tgrd_idx = round_to_int(dTdz / 10);
-      int rhos_idx = round_to_int((rhos - 50) / 50);
-      if (T_idx < 0) T_idx = 0;
-      if (T_idx > 10) T_idx = 10;
-      if (Tgrd_idx < 0) Tgrd_idx = 0;
-      if (Tgrd_idx > 30) Tgrd_idx = 30;
-      if (rhos_idx < 0) rhos_idx = 0;
-      if (rhos_idx > 7) rhos_idx = 7;
-      const int k = (T_idx * 31 + Tgrd_idx) * 8 + rhos_idx;
-      const double bst_tau = tab[k], bst_kappa = tab[ELMK_SNOWAGE_N + k], bst_drdt0 = tab[2 * ELMK_SNOWAGE_N + k];
+      bst_tau[i] = tab[k];
+      bst_kappa[i] = tab[ELMK_SNOWAGE_N + k];
+      bst_drdt0[i] = tab[2 * ELMK_SNOWAGE_N + k];
+    }
+#pragma unroll
+    for (int i = 0; i < NLEVSNO; ++i) {
+      if (i < snl_top) continue;
+      const double liq = AT(K.liq, i), ice = AT(K.ice, i);
+      const double h2osno_lyr = liq + ice;
       const double rds = AT(K.rds, i);
       double dr_fresh = rds - SNW_RDS_MIN;
       if (fabs(dr_fresh) < 1.0e-8) {
@@ -572,7 +594,7 @@ __device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const
       } else if (dr_fresh < 0.0) {
         err |= ELMK_ERR_SNOW_AGE_DRFRESH;
       }
-      double dr = (bst_drdt0 * elmk_pow(bst_tau / (dr_fresh + bst_tau), 1.0 / bst_kappa)) * (dtime / 3600.0);
+      double dr = (bst_drdt0[i] * elmk_pow(bst_tau[i] / (dr_fresh + bst_tau[i]), 1.0 / bst_kappa[i])) * (dtime / 3600.0);
       const double frc_liq = dmin(0.1, (liq / (liq + ice)));
       const double dr_wet = 1.0e18 * (dtime * (C2_liq_Brun89 * elmk_pow(frc_liq, 3.0)) / (4.0 * ELM_PI * elmk_sq(rds)));
       dr += dr_wet;
@@ -582,7 +604,7 @@ __device__ __forceinline__ void snow_aging(const DevState* __restrict__ S, const
       } else {
         newsnow = dmax(0.0, (qflx_snow_grnd * dtime));
       }
-      const double refrzsnow = dmax(0.0, (S->qflx_snofrz_lyr[(int64_t)i * ld + c] * dtime));
+      const double refrzsnow = dmax(0.0, (snofrz_r[i] * dtime));
       double frc_refrz = refrzsnow / h2osno_lyr;
       double frc_newsnow;
       if (i == snl_top) {
@@ -619,6 +641,7 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
   const int64_t ld = S->ld;
   const Land L = S->land;
   const int lane = (int)threadIdx.x;
+  int snl = S->snl[c];  // (first: the per-layer reads further down are only issued for a wave that holds a snow pack)
   // the pack: global rows -> LDS (all loads independent: one batch in flight)
   const dfield g6[5] = {S->h2osoi_liq + c, S->h2osoi_ice + c, S->t_soisno + c, S->dz + c, S->zisoi + c};
   const dfield g5[2 + NAER] = {S->zsoi + c, S->snw_rds + c, S->mss_bcphi + c, S->mss_bcpho + c,
@@ -645,7 +668,6 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
 
   // every per-column scalar of the wrapper, read here beside the pack (the compiler cannot move a load above the stores
   // of an earlier pass, and with one wave per SIMD a load issued where it is used is a stall)
-  int snl = S->snl[c];
   const int do_capsnow = S->do_capsnow[c];
   double frac_sno_eff = S->frac_sno_eff[c], frac_sno = S->frac_sno[c], h2osno = S->h2osno[c], int_snow = S->int_snow[c];
   const double qflx_sub_snow = S->qflx_sub_snow[c];
@@ -662,6 +684,25 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
   for (int i = 0; i < 10; ++i) rootr[i] = S->rootr[(int64_t)i * ld + c];
   const double n_melt = S->n_melt[c];
   double snow_depth = S->snow_depth[c];
+  // the per-layer inputs of snow_compaction (imelt; swe_old on soil / crop land units, frac_iceold elsewhere) and of snow_aging
+  // (qflx_snofrz_lyr): none of them is written here
+  int imelt_r[NLEVSNO];
+  double melt_r[NLEVSNO], snofrz_r[NLEVSNO];
+#pragma unroll
+  for (int i = 0; i < NLEVSNO; ++i) {
+    imelt_r[i] = 0;
+    melt_r[i] = 0.0;
+    snofrz_r[i] = 0.0;
+  }
+  if (__ballot(snl > 0) != 0ull) {  // (wave-uniform; a column without layers reads none of them)
+    const bool soilcrop = (L.ltype == istsoil || L.ltype == istcrop);
+#pragma unroll
+    for (int i = 0; i < NLEVSNO; ++i) {
+      imelt_r[i] = S->imelt[(int64_t)i * ld + c];
+      melt_r[i] = soilcrop ? (double)S->swe_old[(int64_t)i * ld + c] : (double)S->frac_iceold[(int64_t)i * ld + c];
+      snofrz_r[i] = S->qflx_snofrz_lyr[(int64_t)i * ld + c];
+    }
+  }
   const double qflx_snwcp_ice = S->qflx_snwcp_ice[c], qflx_snow_grnd = S->qflx_snow_grnd[c];
 
   snow_water(K, do_capsnow, snl, dtime, frac_sno_eff, h2osno, qflx_sub_snow, qflx_evap_grnd, qflx_dew_snow,
@@ -710,7 +751,7 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
     for (int i = 0; i < 10; ++i) S->qflx_rootsoi[(int64_t)i * ld + c] = rootr[i] * qflx_tran_veg;
   }
 
-  snow_compaction(S, K, c, snl, L.ltype, dtime, int_snow, n_melt, frac_sno);
+  snow_compaction(K, snl, L.ltype, dtime, int_snow, n_melt, frac_sno, imelt_r, melt_r);
 
   double qflx_sl_top_soil, qflx_snow2topsoi, mflx_snowlyr_col;
   combine_layers(K, L.urbpoi != 0, L.ltype, dtime, snl, h2osno, snow_depth, frac_sno_eff, frac_sno, int_snow, qflx_sl_top_soil,
@@ -760,7 +801,7 @@ __global__ __launch_bounds__(SN_WG) void k_snow_hydrology(const DevState* __rest
     }
   }
 
-  snow_aging(S, K, c, do_capsnow, snl, frac_sno, dtime, qflx_snwcp_ice, qflx_snow_grnd, h2osno, err);
+  snow_aging(S, K, do_capsnow, snl, frac_sno, dtime, qflx_snwcp_ice, qflx_snow_grnd, h2osno, snofrz_r, err);
   if (err) S->err_flags[c] |= err;
   // the pack: LDS -> global rows.  Of level 5 only liquid and ice can have changed; temperature, thickness and interface
   // depth of the top soil layer are read-only here.

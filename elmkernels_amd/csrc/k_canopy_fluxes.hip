@@ -579,7 +579,9 @@ __device__ __forceinline__ int cf_class(const DevState* __restrict__ S, const La
 #define CF_COUNT_TILES_N 4
 #endif
 constexpr int CF_COUNT_TILES = CF_COUNT_TILES_N;
-__global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S)
+// (256 x CF_COUNT_TILES threads: the tiles of a workgroup are counted side by side, four waves each - one after the other
+//  their loads were four dependent round trips)
+__global__ __launch_bounds__(256 * CF_COUNT_TILES) void k_cf_count(const DevState* __restrict__ S)
 {
   __shared__ uint32_t s_cnt[CF_COUNT_TILES][CF_NCLS];
   for (int i = threadIdx.x; i < CF_COUNT_TILES * CF_NCLS; i += blockDim.x) (&s_cnt[0][0])[i] = 0u;
@@ -587,9 +589,9 @@ __global__ __launch_bounds__(256) void k_cf_count(const DevState* __restrict__ S
   const Land L = S->land;
   const int lane = threadIdx.x & 63;
   const int64_t tile0 = (int64_t)blockIdx.x * CF_COUNT_TILES;
-#pragma unroll 1
-  for (int t = 0; t < CF_COUNT_TILES; t++) {
-    const int64_t c = (tile0 + t) * 256 + threadIdx.x;
+  {
+    const int t = (int)(threadIdx.x >> 8);
+    const int64_t c = (tile0 + t) * 256 + (threadIdx.x & 255);
     const int cls = L.lakpoi ? -1 : cf_class(S, L, c, c < S->ncols);
 #pragma unroll
     for (int k = 0; k < CF_NCLS; k++) {
@@ -1803,7 +1805,7 @@ void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t s
 {
   if (n <= 0) return;
   const unsigned nblk = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_cf_count, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256), 0, st, S);
+  hipLaunchKernelGGL(k_cf_count, dim3((nblk + CF_COUNT_TILES - 1) / CF_COUNT_TILES), dim3(256 * CF_COUNT_TILES), 0, st, S);
   hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S, given);
   // persistent: two waves per SIMD are resident at this kernel's register and LDS footprint (2 workgroups per CU, 512 in
   // all); workgroups that start later find the queue empty

@@ -303,6 +303,40 @@ static void launch_snicar_deep(const DevState* S, const unsigned capped, const i
 {
   hipLaunchKernelGGL(k_alb_snicar<NL>, dim3(capped), dim3(256), 0, st, S);
 }
+// The four queues of 5..2 layers as ONE launch: the first `per_queue` workgroups take the five-layer queue, the next the
+// four-layer queue, ...; every launch costs ~4.5 us whether its queue holds columns or not (four empty queues on a snow-free
+// region were 18 us of the wrapper), and a queue's tail overlaps the next queue's start.  The price: one register allocation
+// for all (the five-layer body's), which takes the two-layer queue from three waves per SIMD to two.
+#ifndef ALB_DEEP_MERGED
+#define ALB_DEEP_MERGED 1
+#endif
+#ifndef ALB_DEEP_PER_QUEUE
+#define ALB_DEEP_PER_QUEUE 1024
+#endif
+__global__ __launch_bounds__(256, 2) void k_alb_snicar_deep(const DevState* __restrict__ S, const unsigned per_queue)
+{
+  const unsigned q = blockIdx.x / per_queue, b = blockIdx.x - q * per_queue;
+  switch (q) {
+    case 0: snicar_workgroup<5>(S, b, per_queue); break;
+    case 1: snicar_workgroup<4>(S, b, per_queue); break;
+    case 2: snicar_workgroup<3>(S, b, per_queue); break;
+    default: snicar_workgroup<2>(S, b, per_queue);
+  }
+}
+static void launch_snicar_deep_all(const DevState* S, const unsigned capped, const int64_t n, hipStream_t st)
+{
+  if (ALB_DEEP_MERGED) {
+    // (workgroups walk their queue with a stride, so fewer of them do the same work; an empty queue costs what its workgroups
+    //  cost to dispatch - 16 384 of them 14 us, 4 096 the 4.7 us of any launch)
+    const unsigned per_queue = capped < (unsigned)ALB_DEEP_PER_QUEUE ? capped : (unsigned)ALB_DEEP_PER_QUEUE;
+    hipLaunchKernelGGL(k_alb_snicar_deep, dim3(4u * per_queue), dim3(256), 0, st, S, per_queue);
+  } else {
+    launch_snicar_deep<5>(S, capped, n, st);
+    launch_snicar_deep<4>(S, capped, n, st);
+    launch_snicar_deep<3>(S, capped, n, st);
+    launch_snicar_deep<2>(S, capped, n, st);
+  }
+}
 
 // =====================================================================================================
 // stage 3 (coalesced, every column): night defaults (init_timestep), or for a sunlit column ground_albedo,
@@ -388,10 +422,7 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
   // costs a few microseconds, so the launches simply follow each other; the fork and join through side streams cost
   // ~35 us of dependency latency per call and only pay when the queues are too short to fill the machine.
   if (n >= 262144) {
-    launch_snicar_deep<5>(S, capped, n, st);
-    launch_snicar_deep<4>(S, capped, n, st);
-    launch_snicar_deep<3>(S, capped, n, st);
-    launch_snicar_deep<2>(S, capped, n, st);
+    launch_snicar_deep_all(S, capped, n, st);
     hipLaunchKernelGGL(k_alb_snicar<1>, dim3(capped), block, 0, st, S);
   } else {
     (void)hipEventRecord(side->fork, st);
@@ -419,10 +450,7 @@ void launch_albedo_snicar_part(const DevState* S, int64_t n, hipStream_t st, int
   const unsigned capped = want < 4096u ? want : 4096u;
   if (snicar_grid) *snicar_grid = capped;
   if (part == 0) {
-    launch_snicar_deep<5>(S, capped, n, st);
-    launch_snicar_deep<4>(S, capped, n, st);
-    launch_snicar_deep<3>(S, capped, n, st);
-    launch_snicar_deep<2>(S, capped, n, st);
+    launch_snicar_deep_all(S, capped, n, st);
   } else {
     hipLaunchKernelGGL(k_alb_final, dim3((unsigned)((n + 255) / 256)), block, 0, st, S);
   }

@@ -199,20 +199,35 @@ __global__ __launch_bounds__(256) void k_copy(const double* __restrict__ src, do
 
 // several such copies as ONE launch (elmk_restore_fields: a step of the benchmark restores four 8 MB fields, and four
 // launches of 15 us each - latency, not bytes - were 2.6 % of the step)
+// W = words of 8 bytes per thread (2: one 16-byte access per lane, half the workgroups - every field row is a multiple of
+// 256 bytes on a 256-byte boundary, so the odd case only exists for callers with other buffers)
+template <int W>
 __global__ __launch_bounds__(256) void k_copy_multi(const CopyJobs J)
 {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W;
   if (i >= J.end[J.n - 1]) return;
   int j = 0;
   while (i >= J.end[j]) j++;  // (n <= COPY_JOBS_MAX: a handful of scalar compares)
   const int64_t k = i - (j ? J.end[j - 1] : 0);
-  J.dst[j][k] = J.src[j][k];
+  if (W == 2) {
+    *reinterpret_cast<double2*>(J.dst[j] + k) = *reinterpret_cast<const double2*>(J.src[j] + k);
+  } else {
+    J.dst[j][k] = J.src[j][k];
+  }
 }
 
 void launch_copy_multi(const CopyJobs& J, hipStream_t st)
 {
   if (J.n <= 0 || J.end[J.n - 1] <= 0) return;
-  hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)((J.end[J.n - 1] + 255) / 256)), dim3(256), 0, st, J);
+  bool wide = true;
+  for (int j = 0; j < J.n; j++)
+    wide = wide && (J.end[j] % 2 == 0) && ((uintptr_t)J.src[j] % 16 == 0) && ((uintptr_t)J.dst[j] % 16 == 0);
+  const int64_t n = J.end[J.n - 1];
+  if (wide) {
+    hipLaunchKernelGGL(k_copy_multi<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, J);
+  } else {
+    hipLaunchKernelGGL(k_copy_multi<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, J);
+  }
 }
 
 // The same copy in other access shapes (elmk_copy_bandwidth_shape): what bounds a streaming kernel on this chip is how many

@@ -84,13 +84,6 @@ __global__ __launch_bounds__(BG_MAIN_THREADS) void k_bg_main(const DevState* __r
   block_classify_append<1>(S->lists, S->ld, S->counters, LIST_BG, bare ? 0 : -1, (int32_t)c);
 }
 
-__global__ void k_bg_reset(const DevState* __restrict__ S)
-{
-  if (threadIdx.x == 0) {
-    ELMK_LIST_COUNT(S, LIST_BG) = 0u;
-    ELMK_LIST_HEAD(S, LIST_BG) = 0u;
-  }
-}
 
 // stage 2 (bare columns only, from the queue): the Monin-Obukhov iteration and the fluxes
 __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S, const int given)
@@ -185,6 +178,20 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S,
   S->q_ref2m[c] = q_ref2m;
   S->rh_ref2m[c] = dmin(100.0, (q_ref2m / qsat_ref2m * 100.0));
   }
+  // The list is left empty for the next call by the last workgroup that had entries to work on (every launch costs ~4.5 us:
+  // a reset kernel in front of k_bg_main was a quarter of this wrapper on a vegetated region).  The workgroups that find no
+  // entry - all of them when there is no bare column - touch nothing: the count they read is already what a reset would
+  // write.  The list's unused queue-head word counts the workgroups that are done.
+  const uint32_t nwork = (count + 255u) / 256u;
+  const uint32_t participants = nwork < gridDim.x ? nwork : gridDim.x;
+  // (no fence: the only thing the reset is ordered against is the workgroups' read of the count at their start, which the
+  //  use of its value has long completed; a release fence here writes back the XCD's L2 once per workgroup - +75 us measured)
+  if (blockIdx.x < participants && threadIdx.x == 0) {
+    if (atomicAdd(ELMK_GENERIC(&ELMK_LIST_HEAD(S, LIST_BG)), 1u) == participants - 1u) {
+      ELMK_LIST_COUNT(S, LIST_BG) = 0u;
+      ELMK_LIST_HEAD(S, LIST_BG) = 0u;
+    }
+  }
 }
 
 // ---- host launchers ---------------------------------------------------------------------------------
@@ -218,7 +225,6 @@ void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int 
 {
   if (n <= 0) return;
   const unsigned full = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_bg_reset, dim3(1), dim3(64), 0, st, S);
   hipLaunchKernelGGL(k_bg_main, dim3((unsigned)((n + BG_MAIN_THREADS - 1) / BG_MAIN_THREADS)), dim3(BG_MAIN_THREADS), 0, st, S);
   hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, given);
 }

@@ -1123,6 +1123,17 @@ int elmk_read_scratch(elmk_ctx* ctx, int kind, void* host, int64_t offset, int64
   const void* src = nullptr;
   size_t esz = 0;
   int64_t limit = 0;
+  if (kind == ELMK_SCRATCH_LIST_COUNTS) {  // (count, head) of every work list: the counters sit one per 128-byte line
+    if (offset != 0 || count != 2 * NLISTS) return invalid(ctx, "elmk_read_scratch: the list counters are read whole (2 x the number of lists)");
+    std::vector<uint32_t> raw((size_t)2 * NLISTS * CPAD);
+    HIPCHK(hipMemcpyAsync(raw.data(), ELMK_GENERIC(ctx->h.counters), raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < NLISTS; k++) {
+      ((uint32_t*)host)[2 * k] = raw[(size_t)k * CPAD];
+      ((uint32_t*)host)[2 * k + 1] = raw[(size_t)(NLISTS + k) * CPAD];
+    }
+    return ELMK_OK;
+  }
   if (kind == ELMK_SCRATCH_CF_TRIPS || kind == ELMK_SCRATCH_CF_HINTS) {
     src = ELMK_GENERIC(ctx->h.cf_niter);
     esz = 4;

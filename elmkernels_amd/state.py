@@ -238,6 +238,13 @@ class ELMState:
         self._chk(self.lib.elmk_read_scratch(self.ctx, 2, out.ctypes.data_as(C.c_void_p), 0, self.ncols), "read_scratch")
         return out
 
+    def work_list_counters(self):
+        """(entries, queue head) of every internal work list [nlists, 2]: all zero between two wrapper calls."""
+        n = 8
+        out = np.zeros(2 * n, dtype=np.uint32)
+        self._chk(self.lib.elmk_read_scratch(self.ctx, 3, out.ctypes.data_as(C.c_void_p), 0, 2 * n), "read_scratch")
+        return out.reshape(n, 2)
+
     def read_work(self, offset, count):
         out = np.zeros(int(count), dtype=np.float64)
         self._chk(self.lib.elmk_read_scratch(self.ctx, 1, out.ctypes.data_as(C.c_void_p), int(offset), int(count)), "read_scratch")

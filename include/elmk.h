@@ -319,7 +319,13 @@ int elmk_profile_steps(elmk_ctx *ctx, int fused, double dt, int nsteps, float *m
  *                          (canopy_fluxes_impl.hh:233-450) in the last elmk_canopy_fluxes call, 0 = not vegetated
  *   ELMK_SCRATCH_WORK:     doubles of the work arrays, raw (development probes)
  * Synchronises the stream. */
-enum { ELMK_SCRATCH_CF_TRIPS = 0, ELMK_SCRATCH_WORK = 1, ELMK_SCRATCH_CF_HINTS = 2 /* int32 per column: the scheduling hint (decaying maximum of the trip count) */ };
+enum {
+  ELMK_SCRATCH_CF_TRIPS = 0,
+  ELMK_SCRATCH_WORK = 1,
+  ELMK_SCRATCH_CF_HINTS = 2,   /* int32 per column: the scheduling hint (decaying maximum of the trip count) */
+  ELMK_SCRATCH_LIST_COUNTS = 3 /* uint32 x 2 per internal work list: entries, queue head.  Every list is left empty by the
+                                  wrapper that filled it, so both read 0 between two calls (a test asserts it) */
+};
 int elmk_read_scratch(elmk_ctx *ctx, int kind, void *host, int64_t offset, int64_t count);
 /* device-to-device copy bandwidth probe (read+write bytes / s) on this context's device, used as the
  * empirical HBM line next to the 8 TB/s datasheet peak */

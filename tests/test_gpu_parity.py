@@ -828,6 +828,48 @@ def test_error_flags_match_the_reference_throw_sites():
     D.close()
 
 
+def test_work_lists_are_left_empty_between_calls():
+    """Every compacted kernel drains a device-side work list that the same wrapper filled and leaves it empty for the next
+    call (no reset launch in front of it: an empty launch costs 4.5 us).  A list that kept its entries would make the next
+    call append behind them - same results, more and more work - so the counters themselves are checked: the bare-ground
+    list and the five SNICAR queues read (0 entries, head 0) after every wrapper that uses them, per wrapper and fused, on a
+    state that fills all of them."""
+    D, S = _pair(20000, "B", 61)
+    BG, ALB = 1, slice(2, 8)
+
+    def empty(what):
+        c = D.work_list_counters()
+        assert not c[BG].any() and not c[ALB].any(), (what, c.tolist())
+
+    st.kokkos_frac_wet(D)
+    S.frac_wet()
+    for rep in range(2):
+        st.kokkos_albedo_snicar(D)
+        S.albedo_snicar()
+        empty(f"albedo_snicar, call {rep}")
+    st.kokkos_canopy_hydrology(D, DT)
+    st.kokkos_surface_radiation(D)
+    st.kokkos_canopy_temperature(D)
+    S.canopy_hydrology(DT)
+    S.surface_radiation()
+    S.canopy_temperature()
+    for rep in range(3):  # the same wrapper again and again: each call starts from an empty list
+        st.kokkos_bareground_fluxes(D)
+        S.bareground_fluxes()
+        empty(f"bareground_fluxes, call {rep}")
+    st.kokkos_canopy_fluxes(D, DT)
+    S.canopy_fluxes(DT)
+    empty("canopy_fluxes")
+    _check(D, S, "the step made of those calls", bitwise=True)
+    for step in range(2):
+        st.timestep7_fused(D, DT)
+        S.timestep7(DT)
+        empty(f"fused step {step}")
+    _check(D, S, "fused steps after it", bitwise=True)
+    assert (S["frac_veg_nosno"] == 0).sum() > 3000 and (S["snl"] > 1).sum() > 3000  # (the lists were in use)
+    D.close()
+
+
 def test_results_do_not_depend_on_the_schedule():
     """The canopy_fluxes work queue is ordered by the previous call's trip counts (a hint) and filled in workgroup
     arrival order: results must be bit-identical whatever the hint state and the order."""

@@ -575,7 +575,17 @@ def main(argv=None):
         if ndev > 0:
             torch.cuda.set_device(device_index)
         if shared:
-            dist.init_process_group("gloo")
+            # gloo announces its connections on stdout (C++ side): keep stdout for the one JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     red_device = "cpu" if shared else "cuda"

@@ -505,8 +505,8 @@ def test_hot_path_on_device_against_the_reference_library():
     libelmref_canopy.so (the reference's own physics headers, compiled in the build container; the binaries travel to the GPU
     box, /root/reference does not) run the seven wrappers of the step on the host - the oracle's state object is only the
     container of the arrays - and the device runs elmk_timestep7 / elmk_timestep7_fused on the same start state: three chained
-    model steps, 40 000 branch-mix columns with all 24 leafed plant types (C3 and C4), then a soybean land unit: every field
-    bit for bit."""
+    model steps, 40 000 branch-mix columns with all 24 leafed plant types (C3 and C4), then a soybean land unit and the crop,
+    land-ice, deep-lake, wetland and urban land units: every field bit for bit."""
     from oracle import oracle as O
     from tests import _parity_mode
 
@@ -515,7 +515,12 @@ def test_hot_path_on_device_against_the_reference_library():
     if not _parity_mode.BITWISE_VALID:
         pytest.skip("another host libm than the one the device math restates")
     R = O.Reference()
-    for n, seed, land in ((40000, 71, None), (8000, 72, dict(ltype=1, ctype=1, vtype=23, urbpoi=0, lakpoi=0))):
+    for n, seed, land in ((40000, 71, None), (8000, 72, dict(ltype=1, ctype=1, vtype=23, urbpoi=0, lakpoi=0)),
+                          (4000, 73, dict(ltype=2, ctype=0, vtype=15, urbpoi=0, lakpoi=0)),    # crop
+                          (4000, 74, dict(ltype=3, ctype=0, vtype=0, urbpoi=0, lakpoi=0)),     # land ice
+                          (4000, 75, dict(ltype=5, ctype=0, vtype=0, urbpoi=0, lakpoi=1)),     # deep lake
+                          (4000, 76, dict(ltype=6, ctype=0, vtype=0, urbpoi=0, lakpoi=0)),     # wetland
+                          (4000, 77, dict(ltype=7, ctype=71, vtype=0, urbpoi=1, lakpoi=0))):   # urban
         ft = st.field_table()
         cols, scal, soil = synth.make_state(ft, n, tier="B", seed=seed)
         cols["vtype"] = np.random.default_rng(seed).integers(1, 25, n).astype(np.int32)

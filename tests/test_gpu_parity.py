@@ -541,6 +541,48 @@ def test_hot_path_on_device_against_the_reference_library():
         D.close()
 
 
+def test_advance_rows_on_device_against_the_reference_library():
+    """The same for the rows that follow the seven in ELMInterface::advance and that the reference's own functions can run whole:
+    kokkos_init_timestep's column functor, the seven wrappers, kokkos_soil_temperature and kokkos_surface_fluxes, by nothing
+    but oracle/_ref on the host and by the HIP kernels on the device, two chained steps on 20 000 branch-mix columns: every
+    field bit for bit.  (kokkos_snow_hydrology is left out of this chain: two of its ten stages have no reference run.)"""
+    from oracle import oracle as O
+    from tests import _parity_mode
+
+    if not (O.have_ref() and O.have_ref_canopy() and O.lib().ref_soil is not None):
+        pytest.skip("oracle/_ref libraries not built")
+    if not _parity_mode.BITWISE_VALID:
+        pytest.skip("another host libm than the one the device math restates")
+    R = O.Reference()
+    n = 20000
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier="B", seed=81)
+    B = H.oracle_state(cols, scal, soil)
+    D = H.device_state(cols, scal, soil)
+    hgt = {k: B[k].copy() for k in ("forc_hgt_u_patch", "forc_hgt_t_patch", "forc_hgt_q_patch")}
+    for step in range(2):
+        for k, v in hgt.items():
+            D[k] = v
+            B[k][...] = v
+        st.kokkos_init_timestep(D)
+        st.timestep7(D, DT)
+        st.kokkos_soil_temperature(D, DT)
+        st.kokkos_surface_fluxes(D, DT)
+        B.init_timestep(lib=R.R)
+        R.frac_wet(B)
+        B.albedo_snicar_ref()
+        R.canopy_hydrology(B, DT)
+        R.surface_radiation(B)
+        R.canopy_temperature(B)
+        R.bareground_fluxes(B)
+        B.canopy_fluxes_ref(DT)
+        B.soil_temperature_ref(DT)
+        B.surface_fluxes(DT, lib=R.R)
+        assert not (B["err_flags"] >> 31).any(), "the reference threw"
+        _check(D, B, f"HIP vs the reference's own functions, advance rows, step {step}", bitwise=True)
+    D.close()
+
+
 def test_reference_outputs_on_device():
     """HIP directly against outputs of the REFERENCE ITSELF on branch-mix columns (tests/golden/ref_branch_mix.npz, recorded in
     the build container from oracle/_ref by tests/refgolden.py): init_timestep, frac_wet, canopy_hydrology,

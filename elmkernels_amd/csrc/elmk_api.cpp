@@ -86,6 +86,11 @@ struct elmk_ctx {
   bool use_graph = false;
   bool have_init_params = false;
   GraphSlot graph[3];  // [0] elmk_timestep7, [1] elmk_timestep7_fused, [2] elmk_advance_physics
+  // A HIP error may have cut a step short between the kernel that fills a work list and the one that drains it and leaves it
+  // empty (the lists have no reset launch of their own): the next physics call zeroes every list counter first.
+  bool lists_stale = false;
+  char* counters_raw = nullptr;
+  size_t counters_bytes = 0;
   std::string err;
 };
 
@@ -96,7 +101,10 @@ bool hip_fail(elmk_ctx* ctx, hipError_t e, const char* what)
   if (e == hipSuccess) return false;
   char buf[512];
   snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-  if (ctx) ctx->err = buf;
+  if (ctx) {
+    ctx->err = buf;
+    ctx->lists_stale = true;
+  }
   g_create_error = buf;
   return true;
 }
@@ -266,6 +274,8 @@ int elmk_create(int64_t ncols, int device_id, elmk_ctx** out)
   h.wk = (gptr<double>)ctx->scratch;
   h.lists = (gptr<int32_t>)(ctx->scratch + wk_bytes);
   h.counters = (gptr<uint32_t>)(ctx->scratch + wk_bytes + list_bytes);
+  ctx->counters_raw = ctx->scratch + wk_bytes + list_bytes;
+  ctx->counters_bytes = cnt_bytes;
   h.cf_niter = (gptr<int32_t>)(ctx->scratch + wk_bytes + list_bytes + cnt_bytes);
   {
     char* q = ctx->scratch + wk_bytes + list_bytes + cnt_bytes + hint_bytes;
@@ -398,6 +408,14 @@ static int xfer(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, i
   if (!field_ok(field) || (!host && n > 0) || col0 < 0 || n < 0 || col0 + n > ctx->ncols)
     return invalid(ctx, "elmk_upload/download: bad field or column range");
   if (n == 0) return ELMK_OK;
+  // snl indexes the level arrays (top = nlevsno - snl) in every snow and soil kernel, in global memory and in LDS packs: a
+  // value outside 0..nlevsno is refused at the two doors host values come through (here and elmk_fill) instead of being read
+  // out of bounds on the device (the reference has the same undefined behaviour, but no such door)
+  if (up && field == ELMK_FIELD_snl) {
+    const int32_t* v = (const int32_t*)host;
+    for (int64_t i = 0; i < n; i++)
+      if (v[i] < 0 || v[i] > NLEVSNO) return invalid(ctx, "elmk_upload: snl outside 0..nlevsno");
+  }
   if (kStateF32 && g_fields[field].dtype == ELMK_F64) {
     // fp32-state build: the caller's doubles are rounded to the stored fp32 on the way in and widened on the way out (on the
     // host: this build is a measurement variant, its benchmark tiles a small uploaded block on the device)
@@ -453,14 +471,6 @@ static int xfer_stored(elmk_ctx* ctx, int field, void* host, int64_t col0, int64
 
 int elmk_upload(elmk_ctx* ctx, int field, const void* host, int64_t col0, int64_t n, int layout)
 {
-  // snl indexes the level arrays (top = nlevsno - snl) in every snow and soil kernel, in global memory and in LDS packs: a
-  // value outside 0..nlevsno is refused here, at the one door host data comes through, instead of being read out of bounds on
-  // the device (the reference has the same undefined behaviour, but no such door)
-  if (ctx && host && n > 0 && field_ok(field) && field == ELMK_FIELD_snl) {
-    const int32_t* v = (const int32_t*)host;
-    for (int64_t i = 0; i < n; i++)
-      if (v[i] < 0 || v[i] > NLEVSNO) return invalid(ctx, "elmk_upload: snl outside 0..nlevsno");
-  }
   return xfer(ctx, field, const_cast<void*>(host), col0, n, layout, true);
 }
 int elmk_download(elmk_ctx* ctx, int field, void* host, int64_t col0, int64_t n, int layout)
@@ -472,6 +482,8 @@ int elmk_fill(elmk_ctx* ctx, int field, double value)
 {
   if (int rc = enter(ctx)) return rc;
   if (!field_ok(field)) return invalid(ctx, "elmk_fill: bad field");
+  if (field == ELMK_FIELD_snl && !(value >= 0.0 && value <= (double)NLEVSNO))
+    return invalid(ctx, "elmk_fill: snl outside 0..nlevsno");
   launch_fill(ctx->fptr[field], store_dtype(g_fields[field].dtype), g_fields[field].nlev, ctx->ld, ctx->ncols, value, ctx->stream);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
@@ -672,8 +684,18 @@ int elmk_set_snow_age_tables(elmk_ctx* ctx, const double* tau, const double* kap
 // ---------------------------------------------------------------------------------------------------
 // physics wrappers: one launch each, same order/arguments as driver/kokkos
 // ---------------------------------------------------------------------------------------------------
+namespace {
+int heal_lists(elmk_ctx* ctx)
+{
+  if (!ctx->lists_stale) return ELMK_OK;
+  ctx->lists_stale = false;
+  HIPCHK(hipMemsetAsync(ctx->counters_raw, 0, ctx->counters_bytes, ctx->stream));
+  return ELMK_OK;
+}
+}  // namespace
 #define PHYSICS_PROLOGUE()                 \
   if (int rc = enter(ctx)) return rc;      \
+  if (int rc = heal_lists(ctx)) return rc; \
   if (int rc = push_params(ctx)) return rc
 
 int elmk_frac_wet(elmk_ctx* ctx)

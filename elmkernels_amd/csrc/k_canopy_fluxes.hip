@@ -1777,7 +1777,11 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
       break;
     case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;
     case 3:
-      // The bare-ground Monin-Obukhov loop touches bare columns only and the canopy iteration vegetated ones: no field in common.
+      // The bare-ground Monin-Obukhov loop works on bare columns only and the canopy iteration on vegetated ones.  The one field
+      // group both k_bg_flux and k_cf_finish would store to on a bare column is cgrnd / cgrnds / cgrndl (compute_flux of
+      // canopy_fluxes resets them on every column after bareground_fluxes has set them, canopy_fluxes_impl.hh:474-479): in the
+      // fused step k_bg_flux therefore leaves them alone (launch_bareground_list passes given = 4; k_fz_stream has stored the
+      // zeros that are their final value), so the two kernels have no store in common and may run side by side.
       // With FZ_BG_OVERLAP the list kernel goes to a side stream behind k_cf_iterate's launch (case 4): a few hundred workgroups
       // of long dependent chains that cannot fill the machine on their own (VALU busy 0.31 on the branch-mix tier) run in the
       // CUs the persistent iteration kernel frees during its tail, instead of in front of it.

@@ -155,9 +155,14 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S,
   }
   const double cgrnds = raih;
   const double cgrndl = raiw * S->dqgdT[c];
-  S->cgrnds[c] = cgrnds;
-  S->cgrndl[c] = cgrndl;
-  S->cgrnd[c] = cgrnds + S->htvp[c] * cgrndl;
+  // (given & 4: the fused step.  There canopy_fluxes' compute_flux follows in the same call and resets cgrnd* on every column
+  //  (canopy_fluxes_impl.hh:474-479) - k_fz_stream has already stored those zeros - and this kernel may run beside
+  //  k_cf_finish on a side stream: it must not store to a field that kernel stores to.)
+  if (!(given & 4)) {
+    S->cgrnds[c] = cgrnds;
+    S->cgrndl[c] = cgrndl;
+    S->cgrnd[c] = cgrnds + S->htvp[c] * cgrndl;
+  }
   const double eflx_sh_grnd = -raih * dth;
   S->eflx_sh_grnd[c] = eflx_sh_grnd;
   S->eflx_sh_tot[c] = eflx_sh_grnd;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void k_bg_flux(const DevState* __restrict__ S,
   const uint32_t participants = nwork < gridDim.x ? nwork : gridDim.x;
   // (no fence: the only thing the reset is ordered against is the workgroups' read of the count at their start, which the
   //  use of its value has long completed; a release fence here writes back the XCD's L2 once per workgroup - +75 us measured)
+  __syncthreads();  // every wave of this workgroup has read the count before thread 0 may let the last workgroup reset it
   if (blockIdx.x < participants && threadIdx.x == 0) {
     if (atomicAdd(ELMK_GENERIC(&ELMK_LIST_HEAD(S, LIST_BG)), 1u) == participants - 1u) {
       ELMK_LIST_COUNT(S, LIST_BG) = 0u;
@@ -218,7 +224,7 @@ void launch_bareground_list(const DevState* S, int64_t n, hipStream_t st)
 {
   if (n <= 0) return;
   const unsigned full = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, 0);
+  hipLaunchKernelGGL(k_bg_flux, dim3(full < 2048u ? full : 2048u), dim3(256), 0, st, S, 4);
 }
 
 void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int given)

@@ -1076,6 +1076,33 @@ def test_fused_timestep_is_the_same_step(tier, n, seed):
     Fz.close()
 
 
+@pytest.mark.parametrize("tier,n,seed", [("B", 300_000, 98), ("A", 262_144, 99)])
+def test_fused_timestep_large_launch_structure(tier, n, seed):
+    """The launch structure elmk_timestep7_fused only takes at >= 262 144 columns - the single-layer SNICAR queue dealt between
+    k_fz_pre's tiles (k_fz_snicar_pre), the merged deep SNICAR queues, the bare-ground list kernel on a side stream beside
+    k_cf_iterate / k_cf_finish - against elmk_timestep7 and against the oracle: bit-identical in EVERY field (cgrnd / cgrnds /
+    cgrndl, which k_bg_flux and k_cf_finish would both store on a bare column, rootr, btran, tssbef, eff_porosity, the SNICAR
+    products included) over two chained steps.  This is the structure the benchmark runs."""
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier=tier, seed=seed)
+    U = H.device_state(cols, scal, soil)
+    Fz = H.device_state(cols, scal, soil)
+    S = H.oracle_state(cols, scal, soil)
+    for step in range(2):
+        st.timestep7(U, DT)
+        st.timestep7_fused(Fz, DT)
+        S.timestep7(DT)
+        _same_bits(U, Fz, f"fused vs unfused, {tier}/{n}/step {step}")
+        _check(Fz, S, f"fused vs oracle, {tier}/{n}/step {step}", bitwise=True)
+        assert np.array_equal(U.canopy_trip_counts(), Fz.canopy_trip_counts())
+        for name in ("cgrnd", "cgrnds", "cgrndl"):  # canopy_fluxes' compute_flux leaves them 0 on every non-vegetated column
+            assert not Fz[name][S.fields["frac_veg_nosno"] == 0].any(), name
+    c = Fz.work_list_counters()
+    assert not c[1].any() and not c[2:8].any(), ("a work list was left non-empty", c.tolist())
+    U.close()
+    Fz.close()
+
+
 def test_fused_timestep_other_land_units_and_graph():
     """The fused step on the land units that take the short branches (wetland, land ice, lake, urban), mixed with unfused
     steps on the same context (the two launch structures share the queue scratch), and replayed as a HIP graph."""

@@ -109,6 +109,36 @@ template <> struct field_of<ELMK_F64> {
   using type = F32Field;
   static __host__ __device__ type from(void* p) { return F32Field{(gptr<float>)p}; }
 };
+#elif defined(ELMK_STATE_NT)
+// Accesses to an fp64 state field carry the nontemporal hint (global_load / global_store ... nt): a streamed column state is
+// read once and written once per kernel, nothing of it is worth a cache line.  ELMK_STATE_NT is a bit mask chosen per
+// translation unit (Makefile, FLAGS_<file>): 1 = loads, 2 = stores, 3 = both.  The type has the layout of the plain pointer,
+// so DevState is the same block of memory for every translation unit.
+typedef double state_real;
+struct NTRef {
+  gptr<double> p;
+  static __device__ __forceinline__ double ld(gptr<double> q) { return ((ELMK_STATE_NT) & 1) ? __builtin_nontemporal_load(q) : *q; }
+  static __device__ __forceinline__ void st(double v, gptr<double> q)
+  {
+    if ((ELMK_STATE_NT) & 2) __builtin_nontemporal_store(v, q);
+    else *q = v;
+  }
+  __device__ __forceinline__ operator double() const { return ld(p); }
+  __device__ __forceinline__ const NTRef& operator=(double v) const { st(v, p); return *this; }
+  __device__ __forceinline__ const NTRef& operator=(const NTRef& o) const { st(ld(o.p), p); return *this; }
+  __device__ __forceinline__ const NTRef& operator+=(double v) const { st(ld(p) + v, p); return *this; }
+  __device__ __forceinline__ const NTRef& operator-=(double v) const { st(ld(p) - v, p); return *this; }
+  __device__ __forceinline__ const NTRef& operator*=(double v) const { st(ld(p) * v, p); return *this; }
+};
+struct NTField {
+  gptr<double> p;
+  __device__ __forceinline__ NTRef operator[](int64_t i) const { return NTRef{p + i}; }
+  __device__ __forceinline__ NTField operator+(int64_t off) const { return NTField{p + off}; }
+};
+template <> struct field_of<ELMK_F64> {
+  using type = NTField;
+  static __host__ __device__ type from(void* p) { return NTField{(gptr<double>)p}; }
+};
 #else
 typedef double state_real;
 #endif

@@ -117,6 +117,9 @@ class _Lib:
         if self.ref_snow is not None:
             self.ref_snow.elmref_snow_hydrology_stage.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p]
             self.ref_snow.elmref_snow_hydrology_stage.restype = C.c_int
+            if hasattr(self.ref_snow, "elmref_aerosol_helpers"):
+                self.ref_snow.elmref_aerosol_helpers.argtypes = [C.c_int64] + [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 2
+                self.ref_snow.elmref_aerosol_helpers.restype = None
         self.ref_soil = _load(os.path.join(HERE, "_ref", "libelmref_soil.so"))
         if self.ref_soil is not None:
             self.ref_soil.elmref_soil_temperature.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 3
@@ -410,6 +413,17 @@ def psn_counters(reset=False):
     out = (C.c_ulonglong * 4)()
     lib().lib.elmo_psn_counters(out, 1 if reset else 0)
     return dict(zip(("hybrid", "brent", "itmax", "c4"), [int(v) for v in out]))
+
+
+def aerosol_helpers_ref(snow_idx, snotop, do_capsnow, h2osoi_ice, h2osoi_liq, qflx_snwcp_ice, dtime):
+    """ELM::aero_impl::get_snow_mass / get_snowcap_scl_fct (aerosol_physics_impl.hh:10-31) - the reference's own, compiled in
+    oracle/_ref/libelmref_snow.so - elementwise over equally shaped arrays -> (snowmass, snowcap_scl_fct)."""
+    a = [np.ascontiguousarray(x, dtype=t) for x, t in ((snow_idx, np.int32), (snotop, np.int32), (do_capsnow, np.int32),
+                                                      (h2osoi_ice, np.float64), (h2osoi_liq, np.float64), (qflx_snwcp_ice, np.float64))]
+    assert all(x.shape == a[0].shape for x in a)
+    mass, scl = np.zeros(a[0].shape), np.zeros(a[0].shape)
+    lib().ref_snow.elmref_aerosol_helpers(a[0].size, *[x.ctypes.data for x in a], float(dtime), mass.ctypes.data, scl.ctypes.data)
+    return mass, scl
 
 
 def have_ref_canopy():

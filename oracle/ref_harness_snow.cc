@@ -48,6 +48,17 @@ void read_netcdf(const Comm_type& comm, const std::string& filename, const std::
 #include "snow_hydrology.h"
 #include "transpiration.h"
 
+// aerosol_physics.h -> aerosol_physics_impl.hh -> invoke_kernel.hh, whose serial branch names
+// ELM::impl::apply_parallel_for_tuple_impl (:70) and only declares it under ENABLE_KOKKOS (:33-37): the same single declaration of
+// the reference's own entity that ref_harness_soil.cc carries - no body, never instantiated.  With it the header compiles, and
+// its two scalar helpers ELM::aero_impl::get_snow_mass / get_snowcap_scl_fct (aerosol_physics_impl.hh:10-31) - the only
+// arithmetic of update_aerosol_mass_and_concen besides six multiplications by their results - are the reference's own.
+namespace ELM::impl {
+template <typename F, typename T, std::size_t... I>
+constexpr decltype(auto) apply_parallel_for_tuple_impl(F&&, T&&, std::index_sequence<I...>);
+}
+#include "aerosol_physics.h"
+
 #include "elm_oracle.h"
 
 using AD1 = ELM::Array<double, 1>;
@@ -117,4 +128,19 @@ extern "C" int elmref_snow_hydrology_stage(elmo_state* S, double dt, int stage, 
     }
   }
   return threw;
+}
+
+// ELM::aero_impl::get_snow_mass and get_snowcap_scl_fct (aerosol_physics_impl.hh:10-31) over n (layer, column) pairs:
+// snowmass_out[i], scl_out[i] for snow_idx[i], snotop[i], do_capsnow[i], h2osoi_ice[i], h2osoi_liq[i], qflx_snwcp_ice[i].
+// The pin of elmo_aerosol_mass_and_concen (oracle/elmo_physics_g.c): with these two values per layer the rest of
+// update_aerosol_mass_and_concen (:84-103) is `mss *= scl; cnc = mss * (1.0 / snowmass)` on six species.
+extern "C" void elmref_aerosol_helpers(int64_t n, const int* snow_idx, const int* snotop, const int* do_capsnow, const double* h2osoi_ice,
+                                       const double* h2osoi_liq, const double* qflx_snwcp_ice, double dtime, double* snowmass_out,
+                                       double* scl_out)
+{
+  for (int64_t i = 0; i < n; i++) {
+    const double m = ELM::aero_impl::get_snow_mass(snow_idx[i], snotop[i], h2osoi_ice[i], h2osoi_liq[i]);
+    snowmass_out[i] = m;
+    scl_out[i] = ELM::aero_impl::get_snowcap_scl_fct(snow_idx[i], snotop[i], do_capsnow[i], m, qflx_snwcp_ice[i], dtime);
+  }
 }

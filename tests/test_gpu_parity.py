@@ -435,9 +435,18 @@ def test_the_gpu_run_holds_the_bitwise_bar():
     from tests import _parity_mode as M
 
     print("elmk parity bar on this host:", M.REASON)
-    if os.environ.get("ELMK_ALLOW_TOLERANCE") == "1":
-        return
-    assert M.BITWISE_VALID, M.REASON
+    if os.environ.get("ELMK_ALLOW_TOLERANCE") != "1":
+        assert M.BITWISE_VALID, M.REASON
+    # ... nor may the two HIP-vs-reference-library tests silently skip: oracle/_ref/*.so are git-ignored binaries that cannot be
+    # rebuilt on the GPU box (/root/reference does not exist there) - a run from a clean checkout would go green without them.
+    # `python -c "import __graft_entry__ as g; g.build()"` in the build container makes them; ELMK_ALLOW_NO_REF=1 opts out.
+    if os.environ.get("ELMK_ALLOW_NO_REF") != "1":
+        from oracle import oracle as O
+
+        L = O.lib()
+        missing = [n for n, h in (("libelmref.so", L.ref), ("libelmref_canopy.so", L.ref_canopy), ("libelmref_soil.so", L.ref_soil),
+                                  ("libelmref_snow.so", L.ref_snow)) if h is None]
+        assert not missing, f"oracle/_ref/ lacks {missing}: the HIP-vs-reference-library tests would skip (ELMK_ALLOW_NO_REF=1 to allow)"
 
 
 def test_snl_outside_its_range_is_refused_at_upload():

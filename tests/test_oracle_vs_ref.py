@@ -372,12 +372,43 @@ def test_soil_temperature_whole_wrapper_bitwise(soil_states):
 WARN_WATER, WARN_COMBINE, ERR_DIVIDE, ERR_AGE = 1 << 12, 1 << 13, 1 << 14, 1 << 15
 
 
+AERO = ("bcphi", "bcpho", "dst1", "dst2", "dst3", "dst4")
+
+
+def _aerosol_inputs(S):
+    return dict(snl=S["snl"].copy(), cap=S["do_capsnow"].copy(), q=S["qflx_snwcp_ice"].copy(), ice=S["h2osoi_ice"][:, :5].copy(),
+                liq=S["h2osoi_liq"][:, :5].copy(), mss={a: S["mss_" + a].copy() for a in AERO})
+
+
+def _check_aerosol_mass_and_concen(S, a, dt, what):
+    """update_aerosol_mass_and_concen (aerosol_physics_impl.hh:67-106) is a whole-array function whose body is a lambda handed to
+    the Kokkos-only dispatch: it cannot be instantiated here.  Its arithmetic, though, is two scalar helpers - get_snow_mass and
+    get_snowcap_scl_fct (:10-31), which DO compile (ref_harness_snow.cc) - and, per layer and species, `mss *= scl; cnc = mss *
+    (1.0 / snowmass)` (:84-103).  The restatement's stage is pinned through them: the reference's own helper values, the two
+    products formed here in IEEE double, every bit of the twelve arrays compared."""
+    n = a["snl"].shape[0]
+    sl = np.broadcast_to(np.arange(5, dtype=np.int32), (n, 5))
+    top = np.broadcast_to((5 - a["snl"]).astype(np.int32)[:, None], (n, 5))
+    cap = np.broadcast_to(a["cap"].astype(np.int32)[:, None], (n, 5))
+    q = np.broadcast_to(a["q"][:, None], (n, 5))
+    mass, scl = O.aerosol_helpers_ref(sl, top, cap, a["ice"], a["liq"], q, dt)
+    inv = 1.0 / mass
+    for sp in AERO:
+        m = a["mss"][sp] * scl
+        for name, exp in (("mss_" + sp, m), ("cnc_" + sp, m * inv)):
+            got = S[name]
+            eq = (got.view(np.uint64) == exp.view(np.uint64)) | (np.isnan(got) & np.isnan(exp))
+            assert eq.all(), (what, name, int((~eq).sum()))
+    return int((sl >= top).sum())
+
+
 @pytest.mark.skipif(O.lib().ref_snow is None, reason="oracle/_ref/libelmref_snow.so not built here")
 def test_snow_hydrology_stages_bitwise_vs_reference():
     DT = 1800.0
     ft = H.field_table_from_oracle()
     seen_snl_change = {5: 0, 6: 0}
     aged = 0
+    pinned_aero = 0
     compared = {s: 0 for s in O.OracleState.SNOW_STAGES_REF}
     skipped = 0
     for seed in (5, 21):
@@ -393,7 +424,10 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
                 before = S["err_flags"].copy()
                 snl_before = S["snl"].copy()
                 R0_rds = S["snw_rds"].copy()
+                aero_in = _aerosol_inputs(S) if stage == 8 else None
                 S.snow_hydrology_stage(DT, stage)
+                if stage == 8:
+                    pinned_aero += _check_aerosol_mass_and_concen(S, aero_in, DT, (seed, step))
                 if not ref_runs:
                     continue
                 raised = S["err_flags"] & ~before
@@ -419,5 +453,6 @@ def test_snow_hydrology_stages_bitwise_vs_reference():
             S.surface_fluxes(DT)
     # the comparison saw what it is meant to see: layers merged and split, and only a small share of columns was left out
     assert seen_snl_change[5] > 200 and seen_snl_change[6] > 200, seen_snl_change
+    assert pinned_aero > 50000, pinned_aero  # layers inside a pack whose aerosol masses / concentrations were pinned (stage 8)
     assert aged > 8000, aged  # snow_aging grew the grains of the layered packs (table look-ups included)
     assert min(compared.values()) > 40000 and skipped < 0.15 * compared[0], (compared, skipped)  # (five-layer packs: 10 % of tier B)

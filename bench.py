@@ -243,7 +243,7 @@ KERNEL_PREFIX = {
     "fused_stream": ("elmk::k_fz_",),
     "canopy_iterate": ("elmk::k_cf_iterate", "elmk::k_cf_finish"),
 }
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def kernel_source_hash():
@@ -262,9 +262,11 @@ def pmc_traffic(group, tier, cols, table=None):
     read from inside this process, so the number is only reported for the configuration and the build (source hash) it
     was measured on; otherwise None, with the reason on stderr."""
     path = os.path.join(ROOT, "profiles", table or f"{PROFILE_TAG}_hbm_traffic_pmc_tier{tier}.json")
-    if cols != 1_000_000 or not os.path.exists(path) or group not in KERNEL_PREFIX:
+    if not os.path.exists(path) or group not in KERNEL_PREFIX:
         return None
     doc = json.load(open(path))
+    if int(doc.get("columns", 1_000_000)) != cols:
+        return None
     if doc.get("source_hash") not in (None, kernel_source_hash()):
         print(f"bench.py: {os.path.basename(path)} was measured on another build of the kernels: roofline.traffic = null",
               file=sys.stderr)
@@ -313,6 +315,55 @@ def compute_roofline(kernel_names, tier, cols, table=None):
                          (k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_TRANS_F64"])
                          / k["SQ_INSTS_VALU"], 3), "avg_launch_ms_counter_pass": round(secs * 1e3, 4)}
     return out or None
+
+
+# SIMD time per wave64 instruction at two or more waves per SIMD, measured on MI355X (tests/tools/ubench/valu_cost.hip,
+# profiles/r03_valu_issue_cost.txt): fp64 FMA / MUL / ADD 2.2 ns, fp64 rcp / rsq / sqrt 6.9 ns, everything else (32-bit moves and
+# integer ops ~1.0, fp64 compares / ldexp / div helpers ~1.9) taken at 1.0 ns - a lower bound
+VALU_NS = {"fma_mul_add_f64": 2.2, "trans_f64": 6.9, "other": 1.0}
+
+
+def step_floor(tier, cols, step_ms, many_stream_gbps, fused=False):
+    """What the step would take if nothing but the two resources the counters show in use were in the way - VERDICT r03 item 8:
+      bytes_ms = sum over the step's kernels of their PMC-measured HBM bytes / the many-stream copy rate of THIS box (measured in
+                 this run: 64 + 64 separate 8-byte-per-lane streams, what a many-field kernel sees);
+      valu_ms  = sum over the kernels of their VALU wave-instructions x the measured issue cost of their class / 1 024 SIMDs
+                 (per-wrapper step's SQ table; the fused step runs the same arithmetic);
+      floor    = max(bytes_ms, valu_ms): both resources perfectly overlapped across the whole step;
+      serial_floor = sum over kernels of max(bytes_k, valu_k): every kernel at its own roof, no overlap between kernels.
+    frac_of_floor = floor / measured: the rest is lack of overlap between the fp64-bound and the bandwidth-bound phases, lanes
+    idle in issued instructions, tails and launch gaps.  Only for the build and the column count the tables were measured on."""
+    tname = f"{PROFILE_TAG}_hbm_traffic_pmc_{'fused_' if fused else ''}tier{tier}.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    cpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_compute_pmc_tier{tier}.json")
+    if not (os.path.exists(tpath) and os.path.exists(cpath)) or not many_stream_gbps:
+        return None
+    tdoc, cdoc = json.load(open(tpath)), json.load(open(cpath))
+    h = kernel_source_hash()
+    if tdoc.get("source_hash") != h or cdoc.get("source_hash") != h or int(tdoc.get("columns", 1_000_000)) != cols or cols != 1_000_000:
+        return None
+    per = {}
+    for name, v in tdoc["kernels"].items():
+        if name == "elmk::k_copy":
+            continue
+        per[name.replace("elmk::", "")] = [v["hbm_bytes_per_launch"] / (many_stream_gbps * 1e9) * 1e3, 0.0]
+    valu_total = 0.0
+    for name, k in cdoc["kernels"].items():
+        f64 = k["SQ_INSTS_VALU_FMA_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_ADD_F64"]
+        tr = k["SQ_INSTS_VALU_TRANS_F64"]
+        ns = f64 * VALU_NS["fma_mul_add_f64"] + tr * VALU_NS["trans_f64"] + max(k["SQ_INSTS_VALU"] - f64 - tr, 0.0) * VALU_NS["other"]
+        ms = ns / N_SIMD * 1e-6
+        valu_total += ms
+        if name in per:
+            per[name][1] = ms
+    bytes_ms = sum(v[0] for v in per.values())
+    serial = sum(max(v) for v in per.values()) if not fused else None
+    floor = max(bytes_ms, valu_total)
+    return {"bytes_ms": round(bytes_ms, 4), "valu_ms": round(valu_total, 4), "floor_ms": round(floor, 4),
+            "serial_floor_ms": None if serial is None else round(serial, 4), "measured_ms": round(step_ms, 4),
+            "frac_of_floor": round(floor / step_ms, 4), "many_stream_GBps": many_stream_gbps, "valu_ns_per_wave_instruction": VALU_NS,
+            "how": "max(sum of PMC HBM bytes / this box's many-stream copy rate, sum of VALU wave-instructions x measured issue cost / 1024 SIMDs); "
+                   "committed tables of this build (profiles/)"}
 
 
 SOIL_ALGO_BYTES = 2860  # soil_temperature: 1972 B read + 888 B written per column (tally in DESIGN.md section 9)
@@ -409,7 +460,7 @@ def _stop(procs):
 ALGO_BYTES_FUSED_F32 = 1721  # the fused bound with an fp32 state: 3 368 B of fp64 fields halved + 37 B of int / bool fields
 
 
-def fp32_state_variant(device_index, seed, st):
+def fp32_state_variant(device_index, seed, st, compact=False):
     """BASELINE config 5, second half: the fused step on an fp32 STATE (libelmk_f32.so: every fp64 field stored as fp32, all
     arithmetic fp64 - widen on load, round on store), 10 M columns (and 1 M), both tiers.  A report: throughput, the roofline
     against the 1 721 B/column-step bound, PMC traffic and the per-kernel register / occupancy table when the committed tables
@@ -422,25 +473,30 @@ def fp32_state_variant(device_index, seed, st):
     if not os.path.exists(L.F32_LIB_PATH):
         return {"error": "libelmk_f32.so not built"}
     out = {"what": "fused step, fp32-stored state (fp64 arithmetic), libelmk_f32.so; report only", "bytes_per_column_step": ALGO_BYTES_FUSED_F32}
-    for cols_n, key in ((1_000_000, "1M"), (NORTH_STAR_COLS, "10M")):
+    # compact (the default run, so that the driver's command times BASELINE config 5 at its own size): 10 M columns only and a
+    # 50 000-column pair for the error percentiles; --state-f32 adds 1 M columns, a 200 000-column pair and the register table
+    for cols_n, key in (((NORTH_STAR_COLS, "10M"),) if compact else ((1_000_000, "1M"), (NORTH_STAR_COLS, "10M"))):
         for tier in ("A", "B"):
             D, _ = build_state(cols_n, device_index, tier, seed, lib_path=L.F32_LIB_PATH)
-            for _ in range(6):  # (the canopy scheduling hints settle)
+            for _ in range(4 if compact else 6):  # (the canopy scheduling hints settle)
                 D.restore_fields()
                 st.timestep7_fused(D, 1800.0)
-            each = sorted(D.profile_steps(1800.0, 7, fused=True))
+            each = sorted(D.profile_steps(1800.0, 5 if compact else 7, fused=True))
             med = each[len(each) // 2]
-            ms, tot = D.profile_timestep7_fused(1800.0, 5)
+            ms, tot = D.profile_timestep7_fused(1800.0, 3 if compact else 5)
             rec = {"value": cols_n / (med * 1e-3), "unit": "gridcell-timesteps/s", "ms_per_step_median_events": med,
                    "frac_of_fp32_fused_bound": ALGO_BYTES_FUSED_F32 * cols_n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "launch_groups_ms": {k: round(m, 4) for k, m in zip(st.KERNEL_NAMES_FUSED, ms)}, "device_state_GB": round(D.device_bytes / 1e9, 3)}
             if cols_n == 1_000_000:
-                tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_fused_f32_tier{tier}.json")
+                tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_fused_f32_tier{tier}.json", cols_n)
+                rec["traffic_bytes_per_column_step"] = None if tr is None else tr / cols_n
+            else:
+                tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_10M_fused_f32_tier{tier}.json", cols_n)
                 rec["traffic_bytes_per_column_step"] = None if tr is None else tr / cols_n
             D.close()
             out.setdefault(key, {})[TIER_NAMES[tier]] = rec
     # one step from identical inputs through both builds, on the device: how far does the fp32 state move the outputs?
-    n = 200_000
+    n = 50_000 if compact else 200_000
     err = {}
     for tier in ("A", "B"):
         D64, _ = build_state(n, device_index, tier, seed)
@@ -465,7 +521,7 @@ def fp32_state_variant(device_index, seed, st):
         D32.close()
     out["relative_difference_to_fp64_state_after_one_step"] = err
     occ = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_resources.json")
-    if os.path.exists(occ):
+    if os.path.exists(occ) and not compact:
         doc = json.load(open(occ))
         if doc.get("source_hash") == kernel_source_hash():
             out["registers_and_occupancy"] = doc["kernels"]
@@ -479,13 +535,16 @@ FP32_STUDY_FIELDS = ["t_veg", "t_grnd", "h2ocan", "btran", "qflx_tran_veg", "qfl
                      "tssbef", "rootr", "eff_porosity", "fwet", "fdry"]
 
 
-def pmc_traffic_total(table):
-    """Sum over all physics kernels of a committed PMC traffic table (bytes per launch), if it belongs to this build."""
+def pmc_traffic_total(table, cols=None):
+    """Sum over all physics kernels of a committed PMC traffic table (bytes per launch), if it belongs to this build (and, when
+    cols is given, to that column count)."""
     path = os.path.join(ROOT, "profiles", table)
     if not os.path.exists(path):
         return None
     doc = json.load(open(path))
     if doc.get("source_hash") not in (None, kernel_source_hash()):
+        return None
+    if cols is not None and int(doc.get("columns", 1_000_000)) != cols:
         return None
     return float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k != "elmk::k_copy"))
 
@@ -570,6 +629,7 @@ def main(argv=None):
     ap.add_argument("--one-gpu-value", type=float, default=None,
                     help="the 1-GPU `value` of the same configuration: with it the line carries scaling_efficiency = value / (N * that)")
     ap.add_argument("--no-soil-10m", action="store_true", help="skip the soil-column solve at 10 M columns (soil_temperature_10M)")
+    ap.add_argument("--no-state-f32", action="store_true", help="skip the compact fp32-state measurement of the default run (fp32_state_10M)")
     ap.add_argument("--state-f32", action="store_true",
                     help="also measure BASELINE config 5's fp32-state variant (libelmk_f32.so: fp64 fields stored as fp32, fp64 arithmetic, "
                          "fused step) as a separate object fp32_state_10M - reported beside the fp64 numbers, never as `value`")
@@ -758,8 +818,14 @@ def main(argv=None):
                 "kernels_ms": {n: round(m, 4) for n, m in zip(names, msn)},
                 "device_state_GB": round(Dn.device_bytes / 1e9, 3),
             }
+            # PMC HBM bytes of the whole step AT THIS SIZE (profiles/<round>_hbm_traffic_pmc_10M_*: rocprofv3 --pmc passes at 10 M
+            # columns, reported only for the build they were measured on)
+            tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_10M_{'fused_' if args.fused else ''}tier{tier}.json", NORTH_STAR_COLS)
+            north[TIER_NAMES[tier]]["timestep_roofline"]["traffic_bytes_per_column_step"] = None if tr is None else round(tr / NORTH_STAR_COLS, 1)
             if also_fused:
                 north[TIER_NAMES[tier]]["fused_step"] = fused_too(Dn, NORTH_STAR_COLS, 5, 2)
+                tr = pmc_traffic_total(f"{PROFILE_TAG}_hbm_traffic_pmc_10M_fused_tier{tier}.json", NORTH_STAR_COLS)
+                north[TIER_NAMES[tier]]["fused_step"]["traffic_bytes_per_column_step"] = None if tr is None else round(tr / NORTH_STAR_COLS, 1)
             Dn.close()
 
     soil10 = None
@@ -783,8 +849,13 @@ def main(argv=None):
         Ds.close()
 
     f32 = None
-    if solo and args.state_f32 and not soil:
-        f32 = fp32_state_variant(device_index, args.seed, st)
+    if solo and not soil and (args.state_f32 or (not args.no_north_star and not args.no_state_f32 and args.cols < NORTH_STAR_COLS)):
+        if D is not None:
+            D.close()
+            D = None
+        f32 = fp32_state_variant(device_index, args.seed, st, compact=not args.state_f32)
+        if "error" in f32 and not args.state_f32:
+            f32 = None  # (libelmk_f32.so not built: the default run simply has no config-5 object)
 
     if rank == 0:
         value = ncols_global * args.steps / elapsed
@@ -859,11 +930,13 @@ def main(argv=None):
             # are in the kernels that are not streaming kernels (canopy_fluxes' leaf-temperature iteration, SNICAR)
             comp = compute_roofline(["k_cf_iterate", "k_alb_snicar<1>", "k_bg_flux", "k_cf_init", "k_alb_final"], args.tier, args.cols)
             dom_compute = {"canopy_fluxes": "k_cf_iterate", "canopy_iterate": "k_cf_iterate", "albedo_snicar": "k_alb_snicar<1>"}.get(dom[0])
-            bound = "hbm"
+            # `bound` names the roof achieved / peak / frac are measured against (always the HBM line here: the path has no
+            # contraction); `limited_by` says what the counters show the dominant kernel actually waiting for
+            limited_by = "hbm"
             if comp and dom_compute in comp and comp[dom_compute]["valu_busy"] > 0.70:
-                bound = "fp64_valu"
+                limited_by = "fp64_valu"
             out["roofline"] = {
-                "bound": bound, "kernel": f"{dom[0]} ({', '.join(p.replace('elmk::', '') + '*' for p in KERNEL_PREFIX.get(dom[0], ()))})",
+                "bound": "hbm", "limited_by": limited_by, "kernel": f"{dom[0]} ({', '.join(p.replace('elmk::', '') + '*' for p in KERNEL_PREFIX.get(dom[0], ()))})",
                 "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom[0], args.tier, args.cols,
                                        f"{PROFILE_TAG}_hbm_traffic_pmc_fused_tier{args.tier}.json" if args.fused else None),
@@ -875,6 +948,13 @@ def main(argv=None):
                 out["roofline"]["empirical_peak"] = empirical["peak_GBps"]
                 out["roofline"]["frac_of_empirical_peak"] = dom_gbs / empirical["peak_GBps"]
                 out["roofline"]["empirical"] = empirical
+                fl = step_floor(args.tier, args.cols, ms_total, empirical["many_stream_GBps"], fused=args.fused)
+                if fl is not None:
+                    out["roofline"]["floor"] = fl
+            if comp and limited_by == "fp64_valu":
+                c = comp[dom_compute]
+                out["roofline"]["compute"] = {"kernel": dom_compute, "achieved": c["fp64_tflops"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": c["frac_of_fp64_peak"], "valu_busy": c["valu_busy"], "valu_lane_util": c["valu_lane_util"]}
             if comp:
                 out["compute_roofline"] = {"peak_fp64_vector_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "kernels": comp}
             out["timestep_roofline"] = {

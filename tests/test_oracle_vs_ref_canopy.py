@@ -181,6 +181,64 @@ def test_photosynthesis_alone_bitwise_over_wide_inputs():
     assert total["c4"] > 100_000 and total["brent"] > 10_000 and total["itmax"] >= 1, total
 
 
+def test_photosynthesis_throw_sites_are_flagged_exactly_where_the_reference_throws(capfd):
+    """The reference's throw sites in photosynthesis that no model state reaches, reached through
+    photosynthesis() alone with inputs outside physics:
+      * photosynthesis_impl.hh:232 "Negative stomatal conductance": the larger Ball-Berry root is negative only when the
+        humidity or pressure term of the quadratic is - a NEGATIVE vapour pressure of the canopy air (eair < 0), a negative
+        atmospheric pressure, a negative Ball-Berry slope in the plant-type row;
+      * :289 "quadratic solution a == 0.0": a plant-type row with theta_cj = 0 (the co-limitation quadratic's leading coefficient).
+    The reference throws in exactly the calls in which the restatement raises ELMO_ERR_PSN_NEG_GS / ELMO_ERR_PSN_QUADRATIC, and
+    every call that does not throw returns the restatement's bits.  (:439, Brent's bracket check, is unreachable by construction:
+    its only caller, hybrid(), calls brent() inside `if ((f1 < 0 && f0 > 0) || (f1 > 0 && f0 < 0))` (:589-596) with exactly those two
+    values.  surface_albedo_impl.hh:270 cannot fire with nlevcan() == 1 (elm_constants.h:89): canopy_layer_lai has just set tlai_z(0)
+    = elai and tsai_z(0) = esai (:226-229), so both differences are 0 or NaN, never > mpe; :306 sits inside `if (nlevcan() > 1)`.)"""
+    NEG_GS, QUAD = 1 << 2, 1 << 3
+    S = O.OracleState(1)
+    S.load_params()
+    L = O.lib()
+    table = L.lib.elmo_pft_psn_ptr
+    table.restype = C.c_void_p
+    table.argtypes = [C.c_void_p]
+    L.lib.elmo_photosynthesis_batch.argtypes = [C.c_int64] + [C.c_void_p] * 6
+    tab = np.ctypeslib.as_array(C.cast(table(S.ptr), C.POINTER(C.c_double)), shape=(25, 27)).copy()
+    n = 100_000
+    rng = np.random.default_rng(4242)
+    vtype = rng.integers(1, 25, n).astype(np.int32)
+    nrad = np.ones(n, dtype=np.int32)
+
+    def run(x, t):
+        a = np.full((n, 2), -7.0)
+        b = a.copy()
+        err = np.zeros(n, dtype=np.uint32)
+        threw = np.zeros(n, dtype=np.int32)
+        t = np.ascontiguousarray(t)
+        L.lib.elmo_photosynthesis_batch(n, t.ctypes.data, vtype.ctypes.data, nrad.ctypes.data, x.ctypes.data, a.ctypes.data, err.ctypes.data)
+        L.ref_canopy.elmref_photosynthesis(n, t.ctypes.data, vtype.ctypes.data, nrad.ctypes.data, x.ctypes.data, b.ctypes.data, threw.ctypes.data)
+        same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+        assert same[threw == 0].all()
+        return err, threw != 0
+
+    mbb_neg = tab.copy()
+    mbb_neg[:, 17] = -mbb_neg[:, 17]  # mbbopt (pft_data.h:22)
+    cases = [("eair < 0", 7, tab), ("forc_pbot < 0", 3, tab), ("mbbopt < 0", None, mbb_neg)]
+    reached = {}
+    for what, col, t in cases:
+        x = _psn_inputs(rng, n, False)
+        if col is not None:
+            x[:, col] = -x[:, col]
+        err, threw = run(x, t)
+        assert np.array_equal(threw, (err & NEG_GS) != 0) and not (err & QUAD).any(), what
+        reached[what] = int(threw.sum())
+    assert reached["eair < 0"] > 5000 and reached["mbbopt < 0"] > 5000 and reached["forc_pbot < 0"] >= 1, reached
+    theta0 = tab.copy()
+    theta0[:, 15] = 0.0  # theta_cj
+    err, threw = run(_psn_inputs(rng, n, False), theta0)
+    assert np.array_equal(threw, (err & QUAD) != 0) and threw.sum() > 50_000 and not (err & NEG_GS).any()
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()  # (the reference prints its Ball-Berry check to stdout for thousands of these inputs, :240)
+
+
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libelmref.so not built here")
 def test_seven_wrappers_chained_by_the_reference():
     """The whole hot path - ELMInterface::advance's seven calls in its order (elm_kokkos_interface.cc:287-307) - run for four

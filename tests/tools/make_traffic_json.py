@@ -34,6 +34,8 @@ out = {
             "WRITE_SIZE reads them exactly (as MI355X_MICROARCH.md says for wide streams) -> "
             "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.",
     "source_hash": bench.kernel_source_hash(),
+    "columns": cols,
+    "tier": tier,
     "kernels": {},
 }
 for k in sorted(set(fetch) | set(write)):

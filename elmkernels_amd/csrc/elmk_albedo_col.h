@@ -11,6 +11,8 @@ namespace elmk {
 #endif
 
 constexpr double SN_MIN_SNW = 1.0e-30;  // snow_snicar.h:27
+constexpr double SA_MPE = 1.e-06;       // surface_albedo.h:56
+constexpr double SA_EXTKN = 0.30;       // surface_albedo.h:57
 
 // per-column body of stage 1; returns the number of snow layers if the column must go through SNICAR, else 0
 __device__ __forceinline__ int alb_main_column(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L)

@@ -190,7 +190,7 @@ enum : int {
 
 // canopy_fluxes queue records (k_canopy_fluxes.hip): per queue position, SoA [k][position] with stride ld
 constexpr int CF_NCLS = 12;    // scheduling classes: 6 bins of the previous call's trip count x (day, night)
-constexpr int CF_REC_N = 46;   // doubles a column carries into the iteration kernel
+constexpr int CF_REC_N = 43;   // doubles a column carries into the iteration kernel
 constexpr int CF_IREC_N = 3;   // int32: vtype, nrad, frac_veg_nosno
 constexpr int CF_FIN_N = 24;   // doubles the iteration kernel hands to the finishing kernel
 

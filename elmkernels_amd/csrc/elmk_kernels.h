@@ -22,7 +22,8 @@ struct SideStreams {
 // the seven physics launches (one per reference L3 wrapper)
 void launch_frac_wet(const DevState* S, int64_t n, hipStream_t st);
 // classify = false: the caller has run stage 1 (soil albedo, SNICAR queues) itself (the fused step does it in k_fz_prep)
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify = true);
+// final = false: the caller runs stage 3 (k_alb_final's body) itself (the fused step's k_fz_stream)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify = true, bool final = true);
 void launch_albedo_snicar_part(const DevState* S, int64_t n, hipStream_t st, int part, unsigned* snicar_grid);
 void launch_canopy_hydrology(const DevState* S, int64_t n, double dt, hipStream_t st);
 void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);

@@ -7,8 +7,6 @@
 
 namespace elmk {
 
-constexpr double SA_MPE = 1.e-06;   // surface_albedo.h:56
-constexpr double SA_EXTKN = 0.30;   // surface_albedo.h:57
 constexpr int SN_RDS_MAX_TBL = 1500, SN_RDS_MIN_TBL = 30;
 // exp(-argmax), argmax = 10 (snow_snicar_impl.hh:360): the reference's constexpr value, 0x1.7cd79b5647c9bp-15
 constexpr double SN_EXP_MIN = 4.5399929762484854e-05;

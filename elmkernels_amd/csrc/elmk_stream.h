@@ -11,6 +11,7 @@
 // expression, so both forms produce the same bits.  Outputs are always written to the state.
 #pragma once
 #include "elmk_dev.h"
+#include "elmk_albedo_fin.h"
 
 namespace elmk {
 
@@ -408,9 +409,12 @@ __device__ __forceinline__ void canopy_hydrology_col(const DevState* __restrict_
 // canopy_sunshade_fractions :202, initialize_flux :9, total_absorbed_radiation :30, layer_absorbed_radiation :77,
 // reflected_radiation :179 of surface_radiation_impl.hh
 // =====================================================================================================
-template <bool FUSED>
+// ALBFWD (the fused step on a non-urban land unit): the albedo stage's outputs come from registers - a, and flx[i] = {flx_absdv,
+// flx_absdn, flx_absiv, flx_absin}(i) - instead of from the state it has just written them to (AF / AFX below)
+#define AF(field, ib) (ALBFWD ? a.field[ib] : (double)LV(field, ib))
+template <bool FUSED, bool ALBFWD = false>
 __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                                      ColFwd& w)
+                                                      ColFwd& w, const AlbFwd& a, const double (&flx)[6][4])
 {
   const int snl = FW(snl, S->snl[c]);
   double solad[2], solai[2];
@@ -428,13 +432,13 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
     double laisun = 0.0, laisha = 0.0;
     w.nrad = nrad;
     if (nrad > 0) {
-      const double tlai_z = S->tlai_z[c], fsun_z = S->fsun_z[c];
+      const double tlai_z = S->tlai_z[c], fsun_z = ALBFWD ? a.fsun_z : (double)S->fsun_z[c];
       const double laisun_z = tlai_z * fsun_z;
       const double laisha_z = tlai_z * (1.0 - fsun_z);
       laisun += laisun_z;
       laisha += laisha_z;
-      const double parsun_z = solad[0] * S->fabd_sun_z[c] + solai[0] * S->fabi_sun_z[c];
-      const double parsha_z = solad[0] * S->fabd_sha_z[c] + solai[0] * S->fabi_sha_z[c];
+      const double parsun_z = solad[0] * (ALBFWD ? a.fabd_sun_z : (double)S->fabd_sun_z[c]) + solai[0] * (ALBFWD ? a.fabi_sun_z : (double)S->fabi_sun_z[c]);
+      const double parsha_z = solad[0] * (ALBFWD ? a.fabd_sha_z : (double)S->fabd_sha_z[c]) + solai[0] * (ALBFWD ? a.fabi_sha_z : (double)S->fabi_sha_z[c]);
       S->laisun_z[c] = laisun_z;
       S->laisha_z[c] = laisha_z;
       S->parsun_z[c] = parsun_z;
@@ -459,17 +463,17 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
     double trd[2], tri[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {
-      const double cad = solad[ib] * LV(fabd, ib);
-      const double cai = solai[ib] * LV(fabi, ib);
+      const double cad = solad[ib] * AF(fabd, ib);
+      const double cai = solai[ib] * AF(fabi, ib);
       sabv += cad + cai;
       fsa += cad + cai;
-      trd[ib] = solad[ib] * LV(ftdd, ib);
-      tri[ib] = solad[ib] * LV(ftid, ib) + solai[ib] * LV(ftii, ib);
-      double absrad = trd[ib] * (1.0 - LV(albsod, ib)) + tri[ib] * (1.0 - LV(albsoi, ib));
+      trd[ib] = solad[ib] * AF(ftdd, ib);
+      tri[ib] = solad[ib] * AF(ftid, ib) + solai[ib] * AF(ftii, ib);
+      double absrad = trd[ib] * (1.0 - AF(albsod, ib)) + tri[ib] * (1.0 - AF(albsoi, ib));
       sabg_soil += absrad;
-      absrad = trd[ib] * (1.0 - LV(albsnd, ib)) + tri[ib] * (1.0 - LV(albsni, ib));
+      absrad = trd[ib] * (1.0 - AF(albsnd, ib)) + tri[ib] * (1.0 - AF(albsni, ib));
       sabg_snow += absrad;
-      absrad = trd[ib] * (1.0 - LV(albgrd, ib)) + tri[ib] * (1.0 - LV(albgri, ib));
+      absrad = trd[ib] * (1.0 - AF(albgrd, ib)) + tri[ib] * (1.0 - AF(albgri, ib));
       sabg += absrad;
       fsa += absrad;
       if (snl == 0) {
@@ -494,8 +498,8 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
       double sabg_snl_sum = 0.0;
 #pragma unroll
       for (int i = 0; i < NLEVSNO + 1; i++) {
-        lyr[i] = LV(flx_absdv, i) * trd[0] + LV(flx_absdn, i) * trd[1] + LV(flx_absiv, i) * tri[0] +
-                 LV(flx_absin, i) * tri[1];
+        lyr[i] = (ALBFWD ? flx[i][0] : (double)LV(flx_absdv, i)) * trd[0] + (ALBFWD ? flx[i][1] : (double)LV(flx_absdn, i)) * trd[1] +
+                 (ALBFWD ? flx[i][2] : (double)LV(flx_absiv, i)) * tri[0] + (ALBFWD ? flx[i][3] : (double)LV(flx_absin, i)) * tri[1];
         if (i >= NLEVSNO - snl) sabg_snl_sum += lyr[i];
       }
       if (fabs(sabg_snl_sum - sabg_snow) > 0.00001) {
@@ -536,8 +540,8 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
   // ---- reflected_radiation (:179-199)
   double fsr;
   if (!L.urbpoi) {
-    const double rvis = LV(albd, 0) * solad[0] + LV(albi, 0) * solai[0];
-    const double rnir = LV(albd, 1) * solad[1] + LV(albi, 1) * solai[1];
+    const double rvis = AF(albd, 0) * solad[0] + AF(albi, 0) * solai[0];
+    const double rnir = AF(albd, 1) * solad[1] + AF(albi, 1) * solai[1];
     fsr = rvis + rnir;
   } else {
     const double fsr_vis_d = LV(albd, 0) * solad[0];
@@ -548,6 +552,7 @@ __device__ __forceinline__ void surface_radiation_col(const DevState* __restrict
   }
   S->fsr[c] = fsr;
 }
+#undef AF
 
 // =====================================================================================================
 // old_ground_temp :9, ground_temp :32, calc_soilalpha :51, calc_soilbeta :133 (-> surface_resistance_impl.hh:9),

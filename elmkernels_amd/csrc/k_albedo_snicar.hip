@@ -26,243 +26,13 @@
 #include "elmk_kernels.h"
 #include "elmk_albedo_col.h"
 #include "elmk_snicar.h"
+#include "elmk_albedo_fin.h"
 
 namespace elmk {
 
 
-__device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                           const bool day, const double coszen, const double elai, const double esai,
-                                           const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
-                                           const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha);
-
-// ground_albedo (:155-167), flux_absorption_factor (:171-211, subgridflag == 1) and two_stream_solver (:323-687,
-// nlevcan == 1) for one sunlit column, given soil albedos and the SNICAR products; for a column without sun (day ==
-// false) the values surface_albedo::init_timestep leaves (:90-151) and snow_albedo_radiation_factor's "no sun" branch
-// (snow_snicar_impl.hh:758-765).  Every output is STORED BY ALL LANES TOGETHER: a wave that holds sunlit and dark
-// columns would otherwise write every 128-byte line twice, half of it each time (measured: 904 instead of 490 bytes
-// per column written by this kernel on the fixture-tiled state).
-__device__ __forceinline__ void alb_finish(const DevState* __restrict__ S, const int64_t c, const int64_t ld, const Land& L,
-                                           const bool day, const double coszen, const double elai, const double esai,
-                                           const double frac_sno, const double (&albsod)[2], const double (&albsoi)[2],
-                                           const SnowOut& sd, const SnowOut& si, double vcmaxcintsun, double vcmaxcintsha)
-{
-  // ---- ground_albedo (:155-167) and flux_absorption_factor (:171-211, subgridflag == 1)
-  double albgrd[2] = {0.0, 0.0}, albgri[2] = {0.0, 0.0};
-#pragma unroll
-  for (int ib = 0; ib < 2; ib++) {
-    double o_sod = 0.0, o_soi = 0.0, o_snd = 0.0, o_sni = 0.0;
-    if (day) {
-      albgrd[ib] = albsod[ib] * (1.0 - frac_sno) + sd.alb[ib] * frac_sno;
-      albgri[ib] = albsoi[ib] * (1.0 - frac_sno) + si.alb[ib] * frac_sno;
-      o_sod = albsod[ib];
-      o_soi = albsoi[ib];
-      o_snd = sd.alb[ib];
-      o_sni = si.alb[ib];
-    }
-    LV(albsod, ib) = o_sod;
-    LV(albsoi, ib) = o_soi;
-    LV(albsnd, ib) = o_snd;
-    LV(albsni, ib) = o_sni;
-    LV(albgrd, ib) = albgrd[ib];
-    LV(albgri, ib) = albgri[ib];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    double dv = 0.0, dn = 0.0, iv = 0.0, in = 0.0;
-    if (day) {
-      if (L.ltype == istdlak) {
-        dv = sd.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[0]) * (sd.fabs_[i][0] / (1.0 - sd.alb[0])));
-        iv = si.fabs_[i][0] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[0]) * (si.fabs_[i][0] / (1.0 - si.alb[0])));
-        dn = sd.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsod[1]) * (sd.fabs_[i][1] / (1.0 - sd.alb[1])));
-        in = si.fabs_[i][1] * frac_sno + ((1.0 - frac_sno) * (1.0 - albsoi[1]) * (si.fabs_[i][1] / (1.0 - si.alb[1])));
-      } else {
-        dv = sd.fabs_[i][0] * (1.0 - sd.alb[0]);
-        iv = si.fabs_[i][0] * (1.0 - si.alb[0]);
-        dn = sd.fabs_[i][1] * (1.0 - sd.alb[1]);
-        in = si.fabs_[i][1] * (1.0 - si.alb[1]);
-      }
-    }
-    LV(flx_absdv, i) = dv;
-    LV(flx_absdn, i) = dn;
-    LV(flx_absiv, i) = iv;
-    LV(flx_absin, i) = in;
-  }
-
-  // ---- two_stream_solver (:323-687), nlevcan == 1
-  double albd[2], albi[2], ftdd[2], ftid[2], ftii[2], fabd[2], fabi[2], fabi_sun[2], fabi_sha[2];
-  double fsun_z = 0.0, fabd_sun_z = 0.0, fabd_sha_z = 0.0, fabi_sun_z = 0.0, fabi_sha_z = 0.0;
-  const bool soilcrop = (L.ltype == istsoil || L.ltype == istcrop);
-  if (!day) {  // init_timestep's values (:117-135)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      fabd[ib] = 0.0;
-      fabi[ib] = 0.0;
-      fabi_sun[ib] = 0.0;
-      fabi_sha[ib] = 0.0;
-      ftdd[ib] = 0.0;
-      ftid[ib] = 0.0;
-      ftii[ib] = 0.0;
-      albd[ib] = 1.0;
-      albi[ib] = 1.0;
-    }
-  } else if (soilcrop && (elai + esai) > 0.0) {  // vegsol
-    const double* __restrict__ A = S->pft_alb[S->vtype[c]];  // rhol[2] rhos[2] taul[2] taus[2] xl
-    const double t_veg = S->t_veg[c], fwet = S->fwet[c];
-    const double omegas[2] = {0.8, 0.4};
-    const double betads = 0.5, betais = 0.5;
-    const double wl = elai / dmax(elai + esai, SA_MPE);
-    const double ws = esai / dmax(elai + esai, SA_MPE);
-    const double cosz = dmax(0.001, coszen);
-    double chil = dmin(dmax(A[8], -0.4), 0.6);
-    if (fabs(chil) <= 0.01) chil = 0.01;
-    const double phi1 = 0.5 - 0.633 * chil - 0.330 * chil * chil;
-    const double phi2 = 0.877 * (1.0 - 2.0 * phi1);
-    const double gdir = phi1 + phi2 * cosz;
-    const double twostext = gdir / cosz;
-    const double avmu = (1.0 - phi1 / phi2 * elmk_log((phi1 + phi2) / phi1)) / phi2;
-    const double temp0 = gdir + phi2 * cosz;
-    const double temp1 = phi1 * cosz;
-    const double temp2 = (1.0 - temp1 / temp0 * elmk_log((temp1 + temp0) / temp1));
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++) {
-      const double rho = dmax(A[0 + ib] * wl + A[2 + ib] * ws, SA_MPE);
-      const double tau = dmax(A[4 + ib] * wl + A[6 + ib] * ws, SA_MPE);
-      const double omegal = rho + tau;
-      const double asu = 0.5 * omegal * gdir / temp0 * temp2;
-      const double betadl = (1.0 + avmu * twostext) / (omegal * avmu * twostext) * asu;
-      const double betail = 0.5 * ((rho + tau) + (rho - tau) * elmk_sq(((1.0 + chil) / 2.0))) / omegal;
-      double tmp0, tmp1, tmp2;
-      if (t_veg > TFRZ) {
-        tmp0 = omegal;
-        tmp1 = betadl;
-        tmp2 = betail;
-      } else {
-        tmp0 = (1.0 - fwet) * omegal + fwet * omegas[ib];
-        tmp1 = ((1.0 - fwet) * omegal * betadl + fwet * omegas[ib] * betads) / tmp0;
-        tmp2 = ((1.0 - fwet) * omegal * betail + fwet * omegas[ib] * betais) / tmp0;
-      }
-      const double omega = tmp0;
-      const double betad = tmp1;
-      const double betai = tmp2;
-      const double b = 1.0 - omega + omega * betai;
-      const double c1 = omega * betai;
-      tmp0 = avmu * twostext;
-      const double d = tmp0 * omega * betad;
-      const double f = tmp0 * omega * (1.0 - betad);
-      tmp1 = b * b - c1 * c1;
-      const double h = sqrt(tmp1) / avmu;
-      const double sigma = tmp0 * tmp0 - tmp1;
-      const double p1 = b + avmu * h;
-      const double p2 = b - avmu * h;
-      const double p3 = b + tmp0;
-      const double p4 = b - tmp0;
-      double t1 = dmin(h * (elai + esai), 40.0);
-      const double s1 = elmk_exp(-t1);
-      t1 = dmin(twostext * (elai + esai), 40.0);
-      const double s2 = elmk_exp(-t1);
-      // direct beam
-      double u1 = b - c1 / albgrd[ib];
-      double u2 = b - c1 * albgrd[ib];
-      const double u3 = f + c1 * albgrd[ib];
-      tmp2 = u1 - avmu * h;
-      double tmp3 = u1 + avmu * h;
-      double d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
-      double tmp4 = u2 + avmu * h;
-      double tmp5 = u2 - avmu * h;
-      double d2 = tmp4 / s1 - tmp5 * s1;
-      const double h1 = -d * p4 - c1 * f;
-      const double tmp6 = d - h1 * p3 / sigma;
-      const double tmp7 = (d - c1 - h1 / sigma * (u1 + tmp0)) * s2;
-      const double h2 = (tmp6 * tmp2 / s1 - p2 * tmp7) / d1;
-      const double h3 = -(tmp6 * tmp3 * s1 - p1 * tmp7) / d1;
-      const double h4 = -f * p3 - c1 * d;
-      const double tmp8 = h4 / sigma;
-      const double tmp9 = (u3 - tmp8 * (u2 - tmp0)) * s2;
-      const double h5 = -(tmp8 * tmp4 / s1 + tmp9) / d2;
-      const double h6 = (tmp8 * tmp5 * s1 + tmp9) / d2;
-      albd[ib] = h1 / sigma + h2 + h3;
-      ftid[ib] = h4 * s2 / sigma + h5 * s1 + h6 / s1;
-      ftdd[ib] = s2;
-      fabd[ib] = 1.0 - albd[ib] - (1.0 - albgrd[ib]) * ftdd[ib] - (1.0 - albgri[ib]) * ftid[ib];
-      double a1 = h1 / sigma * (1.0 - s2 * s2) / (2.0 * twostext) + h2 * (1.0 - s2 * s1) / (twostext + h) +
-                  h3 * (1.0 - s2 / s1) / (twostext - h);
-      double a2 = h4 / sigma * (1.0 - s2 * s2) / (2.0 * twostext) + h5 * (1.0 - s2 * s1) / (twostext + h) +
-                  h6 * (1.0 - s2 / s1) / (twostext - h);
-      const double fabd_sun = (1.0 - omega) * (1.0 - s2 + 1.0 / avmu * (a1 + a2));
-      const double fabd_sha = fabd[ib] - fabd_sun;  // wrapper-local in the reference (albedo_kokkos.cc:27-28)
-      // diffuse
-      u1 = b - c1 / albgri[ib];
-      u2 = b - c1 * albgri[ib];
-      tmp2 = u1 - avmu * h;
-      tmp3 = u1 + avmu * h;
-      d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
-      tmp4 = u2 + avmu * h;
-      tmp5 = u2 - avmu * h;
-      d2 = tmp4 / s1 - tmp5 * s1;
-      const double h7 = (c1 * tmp2) / (d1 * s1);
-      const double h8 = (-c1 * tmp3 * s1) / d1;
-      const double h9 = tmp4 / (d2 * s1);
-      const double h10 = (-tmp5 * s1) / d2;
-      albi[ib] = h7 + h8;
-      ftii[ib] = h9 * s1 + h10 / s1;
-      fabi[ib] = 1.0 - albi[ib] - (1.0 - albgri[ib]) * ftii[ib];
-      a1 = h7 * (1.0 - s2 * s1) / (twostext + h) + h8 * (1.0 - s2 / s1) / (twostext - h);
-      a2 = h9 * (1.0 - s2 * s1) / (twostext + h) + h10 * (1.0 - s2 / s1) / (twostext - h);
-      fabi_sun[ib] = (1.0 - omega) / avmu * (a1 + a2);
-      fabi_sha[ib] = fabi[ib] - fabi_sun[ib];
-      if (ib == 0) {
-        fsun_z = (1.0 - s2) / t1;
-        const double laisum = elai + esai;
-        fabd_sun_z = fabd_sun / (fsun_z * laisum);
-        fabi_sun_z = fabi_sun[ib] / (fsun_z * laisum);
-        fabd_sha_z = fabd_sha / ((1.0 - fsun_z) * laisum);
-        fabi_sha_z = fabi_sha[ib] / ((1.0 - fsun_z) * laisum);
-        const double extkb = twostext;
-        vcmaxcintsun = (1.0 - elmk_exp(-(SA_EXTKN + extkb) * elai)) / (SA_EXTKN + extkb);
-        vcmaxcintsha = (1.0 - elmk_exp(-SA_EXTKN * elai)) / SA_EXTKN - vcmaxcintsun;
-        if (elai > 0.0) {
-          vcmaxcintsun = vcmaxcintsun / (fsun_z * elai);
-          vcmaxcintsha = vcmaxcintsha / ((1.0 - fsun_z) * elai);
-        } else {
-          vcmaxcintsun = 0.0;
-          vcmaxcintsha = 0.0;
-        }
-      }
-    }
-  } else {  // novegsol (:672-686)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      fabd[ib] = 0.0;
-      fabi[ib] = 0.0;
-      fabi_sun[ib] = 0.0;
-      fabi_sha[ib] = 0.0;
-      ftdd[ib] = 1.0;
-      ftid[ib] = 0.0;
-      ftii[ib] = 1.0;
-      albd[ib] = albgrd[ib];
-      albi[ib] = albgri[ib];
-    }
-  }
-#pragma unroll
-  for (int ib = 0; ib < 2; ib++) {
-    LV(albd, ib) = albd[ib];
-    LV(albi, ib) = albi[ib];
-    LV(ftdd, ib) = ftdd[ib];
-    LV(ftid, ib) = ftid[ib];
-    LV(ftii, ib) = ftii[ib];
-    LV(fabd, ib) = fabd[ib];
-    LV(fabi, ib) = fabi[ib];
-    LV(fabi_sun, ib) = fabi_sun[ib];
-    LV(fabi_sha, ib) = fabi_sha[ib];
-  }
-  S->vcmaxcintsun[c] = vcmaxcintsun;
-  S->vcmaxcintsha[c] = vcmaxcintsha;
-  S->fsun_z[c] = fsun_z;
-  S->fabd_sun_z[c] = fabd_sun_z;
-  S->fabd_sha_z[c] = fabd_sha_z;
-  S->fabi_sun_z[c] = fabi_sun_z;
-  S->fabi_sha_z[c] = fabi_sha_z;
-}
+// (stage 3's per-column pieces - ground_albedo, flux_absorption_factor, two_stream_solver - live in elmk_albedo_fin.h: the fused
+//  step's k_fz_stream runs the same source around surface_radiation's body)
 
 // =====================================================================================================
 // stage 1 (coalesced, every column): canopy_layer_lai, soil albedo of the sunlit columns, and the classification of
@@ -355,58 +125,15 @@ __global__ __launch_bounds__(256) void k_alb_final(const DevState* __restrict__ 
     ELMK_LIST_HEAD(S, LIST_ALB_0 + threadIdx.x) = 0u;
   }
   if (L.urbpoi || c >= S->ncols) return;
-  const double coszen = S->coszen[c];
-  const double elai = S->elai[c];
-  // init_timestep values of the leaf-to-canopy scaling coefficients (overwritten by two_stream where vegetated)
-  double vcmaxcintsun = 0.0;
-  double vcmaxcintsha = (1.0 - elmk_exp(-SA_EXTKN * elai)) / SA_EXTKN;
-  if (elai > 0.0) {
-    vcmaxcintsha /= elai;
-  } else {
-    vcmaxcintsha = 0.0;
-  }
-  const bool day = coszen > 0.0;  // nothing after init_timestep runs without sun except snow_albedo_radiation_factor's
-                                  // "no sun" branch (:758-765): alb_finish stores those values for the dark lanes
-  double albsod[2] = {0.0, 0.0}, albsoi[2] = {0.0, 0.0};
-  double esai = 0.0, frac_sno = 0.0;
-  SnowOut sd, si;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    sd.fabs_[i][0] = sd.fabs_[i][1] = 0.0;
-    si.fabs_[i][0] = si.fabs_[i][1] = 0.0;
-  }
-  sd.alb[0] = sd.alb[1] = si.alb[0] = si.alb[1] = 0.0;
-  if (day) {
-    esai = S->esai[c];
-    frac_sno = S->frac_sno[c];
-    const double h2osno = S->h2osno[c];
-    albsod[0] = LV(albsod, 0);  // written by stage 1
-    albsod[1] = LV(albsod, 1);
-    albsoi[0] = LV(albsoi, 0);
-    albsoi[1] = LV(albsoi, 1);
-    if (h2osno > SN_MIN_SNW) {
-      const gptr<const double> o = S->alb_snow + c;
-      sd.alb[0] = o[0];
-      sd.alb[1] = o[ld];
-      si.alb[0] = o[(int64_t)14 * ld];
-      si.alb[1] = o[(int64_t)15 * ld];
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        sd.fabs_[i][0] = o[(int64_t)(2 + 2 * i) * ld];
-        sd.fabs_[i][1] = o[(int64_t)(3 + 2 * i) * ld];
-        si.fabs_[i][0] = o[(int64_t)(16 + 2 * i) * ld];
-        si.fabs_[i][1] = o[(int64_t)(17 + 2 * i) * ld];
-      }
-    } else if (h2osno < SN_MIN_SNW && h2osno > 0.0) {
-      // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
-      sd.alb[0] = si.alb[0] = albsoi[0];
-      sd.alb[1] = si.alb[1] = albsoi[1];
-    }
-  }
-  alb_finish(S, c, ld, L, day, coszen, elai, esai, frac_sno, albsod, albsoi, sd, si, vcmaxcintsun, vcmaxcintsha);
+  const AlbIn x = alb_final_inputs(S, c, ld, S->frac_sno[c], S->h2osno[c]);
+  AlbFwd a;
+  double flx[6][4];
+  alb_ground(S, c, ld, x.day, x.frac_sno, x.albsod, x.albsoi, x.sd_alb, x.si_alb, a);
+  alb_flux_abs_all(S, c, ld, L, x, flx);
+  alb_two_stream(S, c, ld, L, x.day, x.coszen, x.elai, x.esai, x.vcmaxcintsun, x.vcmaxcintsha, a);
 }
 
-void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify)
+void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const SideStreams* side, bool classify, bool final)
 {
   if (n <= 0) return;
   const dim3 block(256);
@@ -437,7 +164,7 @@ void launch_albedo_snicar(const DevState* S, int64_t n, hipStream_t st, const Si
       (void)hipStreamWaitEvent(st, side->join[i], 0);
     }
   }
-  hipLaunchKernelGGL(k_alb_final, dim3(full), block, 0, st, S);
+  if (final) hipLaunchKernelGGL(k_alb_final, dim3(full), block, 0, st, S);
 }
 
 // The same stage in two parts around a kernel of the caller's that does the single-layer SNICAR queue itself (the fused step's

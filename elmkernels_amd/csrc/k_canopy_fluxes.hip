@@ -494,11 +494,14 @@ constexpr int CF_BLOCK_EXTRA = 24;  // queue positions a wave claims beyond what
 
 // doubles of a queue record (k_cf_init -> k_cf_iterate): the column's inputs of the iteration that are not recomputed
 // from other record fields at a few instructions each when the column is loaded (w_lai, cf, cp25, the t10 terms, qsat of
-// the start temperature) or per plant functional type at kernel start (PFT_* below)
+// the start temperature) or per plant functional type at kernel start (PFT_* below).  Operands that only ever enter a trip
+// combined are stored combined - same operations on the same operands, done by the writer: zl_x = hgt_x - displa of the three
+// profiles (canopy_fluxes_impl.hh:235-238; zl_q repeats zl_t's subtraction when the two heights are equal, and that they are
+// travels as bit 8 of the record's frac_veg_nosno word), rad_in = sabv + air and lw_term = cir * lw_grnd of :391-392 / :399-401.
 #define CF_REC_FIELDS(X)                                                                                               \
   X(forc_pbot) X(forc_q) X(forc_th) X(forc_rho) X(thm) X(thv) X(elai) X(esai) X(qg) X(t_grnd) X(z0mg) X(z0mv)          \
-  X(hgt_u) X(hgt_t) X(hgt_q) X(displa) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha) X(rdl_num) X(soilbeta)        \
-  X(sabv) X(h2ocan) X(air) X(bir) X(cir) X(lw_grnd) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun) X(parsha) X(lai_sun_z)   \
+  X(zl_u) X(zl_t) X(zl_q) X(ur) X(htop) X(fwet) X(fdry) X(laisun) X(laisha) X(rdl_num) X(soilbeta)                     \
+  X(rad_in) X(h2ocan) X(bir) X(lw_term) X(vcmaxcintsun) X(vcmaxcintsha) X(parsun) X(parsha) X(lai_sun_z)               \
   X(lai_sha_z) X(t10) X(vcmaxc) X(jmaxc) X(tpuc) X(t_veg) X(btran) X(um) X(obu)                                       \
   X(forc_po2) X(forc_pco2) /* only written and read by the L2-level entry elmk_canopy_fluxes_given */
 // doubles of a finish record (k_cf_iterate -> k_cf_finish)
@@ -531,10 +534,31 @@ enum : int {
 // Records are stored in blocks of 8 consecutive queue positions: block b holds field k of positions 8b..8b+7 at
 // [b][k][0..7] (64 contiguous bytes), so all fields of neighbouring positions share a few DRAM pages, a refill batch
 // of consecutive positions reads 64-byte runs, and the writers' partial runs merge in L2.
+// CF_REC_AOS / CF_FIN_AOS (development A/B, profiles/r04_record_layout_ab.txt): a record as CF_*_N consecutive doubles at its
+// position - every lane reads or writes ONE contiguous run (16-byte accesses), whatever positions its neighbours hold.
+#ifndef CF_REC_AOS
+#define CF_REC_AOS 0
+#endif
+#ifndef CF_FIN_AOS
+#define CF_FIN_AOS 0
+#endif
+#if CF_REC_AOS
+#define CF_REC_BASE(pos) ((pos) * (int64_t)CF_REC_N)
+#define CF_REC_K(k) (k)
+#else
 #define CF_REC_BASE(pos) (((pos) >> 3) * (int64_t)(CF_REC_N * 8) + ((pos)&7))
+#define CF_REC_K(k) ((k)*8)
+#endif
+#if CF_FIN_AOS
+#define CF_FIN_BASE(pos) ((pos) * (int64_t)CF_FIN_N)
+#define CF_FIN_K(k) (k)
+#else
 #define CF_FIN_BASE(pos) (((pos) >> 3) * (int64_t)(CF_FIN_N * 8) + ((pos)&7))
+#define CF_FIN_K(k) ((k)*8)
+#endif
 static_assert(REC_COUNT == CF_REC_N && FIN_COUNT == CF_FIN_N, "record sizes in elmk_dev.h out of date");
 enum : int { IREC_vtype = 0, IREC_nrad, IREC_fvn };
+constexpr int IREC_FVN_SAME_TQ = 1 << 8;  // in the IREC_fvn word: forc_hgt_q_patch == forc_hgt_t_patch (friction_velocity_humidity's short-cut)
 
 // class totals of the current call: counters behind the list counters, one per 128-byte line; zero on entry
 // (elmk_create clears them, k_cf_finish clears them again for the next call)
@@ -702,7 +726,7 @@ __device__ __forceinline__ void cf_root_stress_col(const DevState* __restrict__ 
     LV(rootr, i) = q;
   }
   S->btran[c] = btran;
-  (S->cf_rec + CF_REC_BASE(pos))[REC_btran * 8] = btran;
+  (S->cf_rec + CF_REC_BASE(pos))[CF_REC_K(REC_btran)] = btran;
 }
 
 // ROOT_DONE: the fused step's early kernel (k_fz_pre) has already done cf_root_stress_col and the bare branch's rootr / btran
@@ -729,7 +753,7 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   // record fields are stored as soon as they are final (PUT), so few of them are live at any time
   CfRec r;
   const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
-#define PUT(n) rec[REC_##n * 8] = r.n;
+#define PUT(n) rec[CF_REC_K(REC_##n)] = r.n;
   const int snl = FW(snl, S->snl[c]);
   const int vtype = S->vtype[c];
   const double* __restrict__ P = S->pft_psn[vtype];
@@ -755,8 +779,6 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   S->z0mv[c] = z0mv;
   S->z0hv[c] = z0mv;
   S->z0qv[c] = z0mv;
-  r.displa = displa;
-  PUT(displa)
   r.z0mv = z0mv;
   PUT(z0mv)
 
@@ -783,12 +805,12 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   PUT(qg)
   r.t_grnd = FW(t_grnd, S->t_grnd[c]);
   PUT(t_grnd)
-  r.hgt_u = FW(hgt_u, S->forc_hgt_u_patch[c]);
-  PUT(hgt_u)
-  r.hgt_t = FW(hgt_t, S->forc_hgt_t_patch[c]);
-  PUT(hgt_t)
-  r.hgt_q = FW(hgt_q, S->forc_hgt_q_patch[c]);
-  PUT(hgt_q)
+  const double hgt_u = FW(hgt_u, S->forc_hgt_u_patch[c]), hgt_t = FW(hgt_t, S->forc_hgt_t_patch[c]), hgt_q = FW(hgt_q, S->forc_hgt_q_patch[c]);
+  const bool same_tq = (hgt_q == hgt_t);
+  r.zl_u = hgt_u - displa;
+  r.zl_t = hgt_t - displa;
+  r.zl_q = same_tq ? (hgt_t - displa) : (hgt_q - displa);
+  PUT(zl_u) PUT(zl_t) PUT(zl_q)
   const double forc_u = S->forc_u[c], forc_v = S->forc_v[c];
   r.ur = dmax(1.0, sqrt(forc_u * forc_u + forc_v * forc_v));
   PUT(ur)
@@ -804,16 +826,15 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   PUT(laisha)
   r.soilbeta = FW(soilbeta, S->soilbeta[c]);
   PUT(soilbeta)
-  r.sabv = FW(sabv, S->sabv[c]);
-  PUT(sabv)
+  const double sabv = FW(sabv, S->sabv[c]);
   r.h2ocan = FW(h2ocan, S->h2ocan[c]);
   PUT(h2ocan)
   const double emv = FW(emv, S->emv[c]), emg = FW(emg, S->emg[c]);
-  r.air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * S->forc_lwrad[c];  // :360-362
+  const double air = emv * (1.0 + (1.0 - emv) * (1.0 - emg)) * S->forc_lwrad[c];  // :360-362
   r.bir = -(2.0 - emv * (1.0 - emg)) * emv * STEBOL;
-  PUT(air) PUT(bir)
-  r.cir = emv * emg * STEBOL;
-  PUT(cir)
+  r.rad_in = sabv + air;
+  PUT(rad_in) PUT(bir)
+  const double cir = emv * emg * STEBOL;
   r.vcmaxcintsun = S->vcmaxcintsun[c];
   PUT(vcmaxcintsun)
   r.vcmaxcintsha = S->vcmaxcintsha[c];
@@ -843,7 +864,7 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
     const double dth = r.thm - taf;
     const double dqh = r.forc_q - qaf;
     const double dthv = dth * (1.0 + 0.61 * r.forc_q) + 0.61 * r.forc_th * dqh;
-    const double zldis = r.hgt_u - displa;
+    const double zldis = r.zl_u;
     if (!(zldis >= 0.0)) S->err_flags[c] |= ELMK_ERR_CANFLX_FORC_HGT;
     monin_obukhov_length(r.ur, r.thv, dthv, zldis, z0mv, r.um, r.obu);
     PUT(um) PUT(obu)
@@ -851,10 +872,11 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
 
   // ground-emitted longwave (:366-367), loop-invariant
   const double frac_sno = FW(frac_sno, S->frac_sno[c]), frac_h2osfc = FW(frac_h2osfc, S->frac_h2osfc[c]);
-  r.lw_grnd = (frac_sno * elmk_pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * elmk_pow(t_soi0, 4.0) +
-               frac_h2osfc * elmk_pow(FW(t_h2osfc, S->t_h2osfc[c]), 4.0));
-  PUT(lw_grnd)
-  S->wk[(int64_t)WK_CF_LWGRND * ld + c] = r.lw_grnd;
+  const double lw_grnd = (frac_sno * elmk_pow(t_top, 4.0) + (1.0 - frac_sno - frac_h2osfc) * elmk_pow(t_soi0, 4.0) +
+                          frac_h2osfc * elmk_pow(FW(t_h2osfc, S->t_h2osfc[c]), 4.0));
+  r.lw_term = cir * lw_grnd;
+  PUT(lw_term)
+  S->wk[(int64_t)WK_CF_LWGRND * ld + c] = lw_grnd;
 
   // iteration-invariant part of photosynthesis() that needs an exp per column (photosynthesis_impl.hh:46-55); the rest is
   // recomputed by k_cf_iterate when it loads the column (cf_psn_column) or once per plant functional type (cf_pft_row)
@@ -879,7 +901,7 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   const gptr<int32_t> irec = S->cf_irec + pos;
   irec[(int64_t)IREC_vtype * ld] = vtype;
   irec[(int64_t)IREC_nrad * ld] = nrad;
-  irec[(int64_t)IREC_fvn * ld] = FW(fvn, S->frac_veg_nosno[c]);
+  irec[(int64_t)IREC_fvn * ld] = FW(fvn, S->frac_veg_nosno[c]) | (same_tq ? IREC_FVN_SAME_TQ : 0);
 }
 
 __global__ __launch_bounds__(256) void k_cf_init(const DevState* __restrict__ S, const int given)
@@ -1057,16 +1079,17 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
     if (fresh) {
       fresh = false;
       const gptr<const double> rec = S->cf_rec + CF_REC_BASE(pos);
-#define LD(n) rec[REC_##n * 8]
+#define LD(n) rec[CF_REC_K(REC_##n)]
       const gptr<const int32_t> irec = S->cf_irec + pos;
       const int vtype = irec[(int64_t)IREC_vtype * ld];
       nrad = irec[(int64_t)IREC_nrad * ld];
       fvn = irec[(int64_t)IREC_fvn * ld];
+      same_tq = (fvn & IREC_FVN_SAME_TQ) != 0;
+      fvn &= ~IREC_FVN_SAME_TQ;
       PR = s_pft + vtype * PFT_STRIDE;
       c3flag = PR[PFT_c3] != 0.0;
       const double pbot = LD(forc_pbot), thm = LD(thm), t_grnd = LD(t_grnd), forc_q = LD(forc_q), qg = LD(qg);
       const double elai = LD(elai), esai = LD(esai), t10 = LD(t10), parsun = LD(parsun), parsha = LD(parsha);
-      const double displa = LD(displa), hgt_t = LD(hgt_t), hgt_q = LD(hgt_q);
       CSET(forc_pbot, pbot);
       CSET(thm, thm);
       CSET(t_grnd, t_grnd);
@@ -1079,16 +1102,10 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
 #define CP(n) CSET(n, LD(n));
       CP(forc_th) CP(forc_rho) CP(thv) CP(z0mg) CP(z0mv) CP(ur) CP(htop) CP(fwet) CP(fdry) CP(laisun) CP(laisha) CP(rdl_num)
       CP(soilbeta) CP(bir) CP(vcmaxcintsun) CP(vcmaxcintsha) CP(lai_sun_z) CP(lai_sha_z) CP(vcmaxc) CP(jmaxc) CP(tpuc)
+      // (operands that only ever enter a trip combined arrive combined: zl_x, rad_in, lw_term - see CF_REC_FIELDS; h2ocan / dtime
+      // of :338 / :411-412 is formed here, the writer does not know the caller's dtime)
+      CP(zl_u) CP(zl_t) CP(zl_q) CP(rad_in) CP(lw_term)
 #undef CP
-      // operands that only ever enter a trip combined, combined once (same operations in the same order as the trip's
-      // expressions: hgt - displa of the three profiles :235-238, sabv + air and cir * lw_grnd of :391-392 / :399-401,
-      // h2ocan / dtime of :338 / :411-412)
-      CSET(zl_u, LD(hgt_u) - displa);
-      CSET(zl_t, hgt_t - displa);
-      CSET(zl_q, (hgt_q == hgt_t) ? (hgt_t - displa) : (hgt_q - displa));
-      same_tq = (hgt_q == hgt_t);
-      CSET(rad_in, LD(sabv) + LD(air));
-      CSET(lw_term, LD(cir) * LD(lw_grnd));
       CSET(h2ocan_dt, LD(h2ocan) / dtime);
       day = (nrad > 0) && (parsun > 0.0 || parsha > 0.0);
       // what k_cf_init does not hand over: a few instructions each, from the record's own fields
@@ -1098,7 +1115,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
         CSET(tc10, dmin(dmax((t10 - TFRZ), 11.0), 35.0));
         CSET(cf, pbot / (RGAS * 1.0e-3 * thm) * 1.e06);
         const double sco = 0.5 * 0.209 / (42.75 / 1.e06);
-        const double po2 = (given & 6) ? rec[REC_forc_po2 * 8] : derive_forc_po2(pbot);
+        const double po2 = (given & 6) ? rec[CF_REC_K(REC_forc_po2)] : derive_forc_po2(pbot);
         CSET(cp25, 0.5 * po2 / sco);
       }
       // iteration start values (canopy_fluxes_impl.hh:154-166 and :203-215)
@@ -1215,8 +1232,8 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
         double forc_po2 = derive_forc_po2(C(forc_pbot)), forc_pco2 = derive_forc_pco2(C(forc_pbot));
         if (given & 6) {  // (L2-level entry only: the column's own values, kept in its queue record)
           const gptr<const double> grec = S->cf_rec + CF_REC_BASE(pos);
-          forc_po2 = grec[REC_forc_po2 * 8];
-          forc_pco2 = grec[REC_forc_pco2 * 8];
+          forc_po2 = grec[CF_REC_K(REC_forc_po2)];
+          forc_pco2 = grec[CF_REC_K(REC_forc_pco2)];
         }
         PR_T(3)
         rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
@@ -1361,30 +1378,30 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       // ---------------- converged: hand the state to k_cf_finish, release the lane ----------------
       if (stop) {
         const gptr<double> fin = S->cf_fin + CF_FIN_BASE(pos);
-        fin[FIN_t_veg * 8] = t_veg;
-        fin[FIN_btran * 8] = btran;
-        fin[FIN_qflx_tran_veg * 8] = qflx_tran_veg;
-        fin[FIN_qflx_evap_veg * 8] = qflx_evap_veg;
-        fin[FIN_eflx_sh_veg * 8] = eflx_sh_veg;
-        fin[FIN_wtg * 8] = wtg;
-        fin[FIN_wtl0 * 8] = wtl0;
-        fin[FIN_wta0 * 8] = wta0;
-        fin[FIN_wtal * 8] = wtal;
-        fin[FIN_wtgq * 8] = wtgq;
-        fin[FIN_wtalq * 8] = wtalq;
-        fin[FIN_wtlq0 * 8] = wtlq0;
-        fin[FIN_wtaq0 * 8] = wtaq0;
-        fin[FIN_delq * 8] = delq;
-        fin[FIN_qsatl * 8] = qsatl;
-        fin[FIN_temp1 * 8] = temp1;
-        fin[FIN_temp2 * 8] = temp2;
-        fin[FIN_dth * 8] = dth;
-        fin[FIN_dqh * 8] = dqh;
-        fin[FIN_tlbef * 8] = tlbef;
-        fin[FIN_dt_veg * 8] = dt_veg;
-        fin[FIN_obu_trip * 8] = obu_trip;
-        fin[FIN_trips * 8] = (double)itlef;
-        fin[FIN_err * 8] = (double)err;
+        fin[CF_FIN_K(FIN_t_veg)] = t_veg;
+        fin[CF_FIN_K(FIN_btran)] = btran;
+        fin[CF_FIN_K(FIN_qflx_tran_veg)] = qflx_tran_veg;
+        fin[CF_FIN_K(FIN_qflx_evap_veg)] = qflx_evap_veg;
+        fin[CF_FIN_K(FIN_eflx_sh_veg)] = eflx_sh_veg;
+        fin[CF_FIN_K(FIN_wtg)] = wtg;
+        fin[CF_FIN_K(FIN_wtl0)] = wtl0;
+        fin[CF_FIN_K(FIN_wta0)] = wta0;
+        fin[CF_FIN_K(FIN_wtal)] = wtal;
+        fin[CF_FIN_K(FIN_wtgq)] = wtgq;
+        fin[CF_FIN_K(FIN_wtalq)] = wtalq;
+        fin[CF_FIN_K(FIN_wtlq0)] = wtlq0;
+        fin[CF_FIN_K(FIN_wtaq0)] = wtaq0;
+        fin[CF_FIN_K(FIN_delq)] = delq;
+        fin[CF_FIN_K(FIN_qsatl)] = qsatl;
+        fin[CF_FIN_K(FIN_temp1)] = temp1;
+        fin[CF_FIN_K(FIN_temp2)] = temp2;
+        fin[CF_FIN_K(FIN_dth)] = dth;
+        fin[CF_FIN_K(FIN_dqh)] = dqh;
+        fin[CF_FIN_K(FIN_tlbef)] = tlbef;
+        fin[CF_FIN_K(FIN_dt_veg)] = dt_veg;
+        fin[CF_FIN_K(FIN_obu_trip)] = obu_trip;
+        fin[CF_FIN_K(FIN_trips)] = (double)itlef;
+        fin[CF_FIN_K(FIN_err)] = (double)err;
         pos = -1;
       }
       PR_T(8)
@@ -1447,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   }
   CfFin f;
   const gptr<const double> fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
-#define X(n) f.n = fin[FIN_##n * 8];
+#define X(n) f.n = fin[CF_FIN_K(FIN_##n)];
   CF_FIN_FIELDS(X)
 #undef X
   const double t_veg = f.t_veg;
@@ -1704,6 +1721,9 @@ __global__ __launch_bounds__(256, 2) void k_fz_snicar_pre(const DevState* __rest
 #define FZ_SPLIT 2  // 2: k_fz_pre's tiles share a kernel with the single-layer SNICAR queue (k_fz_snicar_pre); 1: k_fz_pre beside
                     // the albedo stage on a side stream; 0: k_fz_stream does that work itself, as in round 2 (1, 0: development A/B)
 #endif
+#ifndef FZ_ALB_FWD
+#define FZ_ALB_FWD 1  // 0: k_alb_final as its own launch in front of k_fz_stream, as in round 3 (development A/B)
+#endif
 __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict__ S, double dtime)
 {
   elmk_math_lds_init<false>();
@@ -1721,9 +1741,39 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
   }
 #endif
   ColFwd w;
+#if FZ_ALB_FWD
+  // Stage 3 of albedo_snicar (k_alb_final's body, elmk_albedo_fin.h) runs HERE, between canopy_hydrology and surface_radiation,
+  // so that surface_radiation takes the 56 doubles it reads of that stage's outputs from registers instead of from the state
+  // (-496 bytes per column and one launch less).  The reference runs albedo BEFORE canopy_hydrology (elm_kokkos_interface.cc:
+  // 292-295), which changes two of its inputs - frac_sno and h2osno (snow_init, fraction_h2osfc) - so their values of before are
+  // taken first; nothing else the stage reads (coszen, elai, esai, t_veg, fwet, the soil albedos, the SNICAR products) is written
+  // by canopy_hydrology, and nothing canopy_hydrology reads is written by the stage.
+  const bool alb_here = inside && !L.urbpoi;  // (kokkos_albedo_snicar does nothing on urban land units)
+  const double frac_sno_before = alb_here ? (double)S->frac_sno[c] : 0.0, h2osno_before = alb_here ? (double)S->h2osno[c] : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < 6) {  // (k_alb_final's job: the SNICAR queues are drained by now, leave them empty)
+    ELMK_LIST_COUNT(S, LIST_ALB_0 + threadIdx.x) = 0u;
+    ELMK_LIST_HEAD(S, LIST_ALB_0 + threadIdx.x) = 0u;
+  }
+#endif
   canopy_hydrology_col<true>(S, c, ld, L, dtime, w, inside);  // (every thread: the pond solves are pooled per workgroup)
   if (inside) {
-    surface_radiation_col<true>(S, c, ld, L, w);
+#if FZ_ALB_FWD
+    AlbFwd a;
+    double flx[6][4];
+    if (alb_here) {
+      const AlbIn x = alb_final_inputs(S, c, ld, frac_sno_before, h2osno_before);
+      alb_ground(S, c, ld, x.day, x.frac_sno, x.albsod, x.albsoi, x.sd_alb, x.si_alb, a);
+      alb_two_stream(S, c, ld, L, x.day, x.coszen, x.elai, x.esai, x.vcmaxcintsun, x.vcmaxcintsha, a);
+      alb_flux_abs_all(S, c, ld, L, x, flx);
+      surface_radiation_col<true, true>(S, c, ld, L, w, a, flx);
+    } else {
+      surface_radiation_col<true, false>(S, c, ld, L, w, a, flx);
+    }
+#else
+    const AlbFwd a{};
+    const double flx[6][4] = {};
+    surface_radiation_col<true>(S, c, ld, L, w, a, flx);
+#endif
     canopy_temperature_col<true, FZ_SPLIT != 0>(S, c, ld, L, w);
   }
   // bareground_fluxes, streaming stage (k_bg_main): compute_flux's unconditional cgrnd reset and the list of bare columns
@@ -1751,7 +1801,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
     case 0: hipLaunchKernelGGL(k_fz_prep, dim3((nblk + FZ_PREP_TILES - 1) / FZ_PREP_TILES), dim3(256), 0, st, S); break;
     case 1:
       if (!FZ_SPLIT) {
-        launch_albedo_snicar(S, n, st, side, false);
+        launch_albedo_snicar(S, n, st, side, false, !FZ_ALB_FWD);
       } else if (FZ_SPLIT == 2 && n >= 262144) {
         // the SNICAR queues of 5..2 layers, then the single-layer queue and k_fz_pre's tiles as ONE kernel, then k_alb_final
         unsigned gs = 0;
@@ -1761,18 +1811,18 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
         // the SNICAR part filled the machine first at 10 M columns and the tiles ran behind it
         if (FZ_SNICAR_GRID_BY_TILES && gs < nblk) gs = nblk;
         hipLaunchKernelGGL(k_fz_snicar_pre, dim3(gs + nblk), dim3(256), 0, st, S, gs, nblk);
-        launch_albedo_snicar_part(S, n, st, 1, nullptr);
+        if (!FZ_ALB_FWD) launch_albedo_snicar_part(S, n, st, 1, nullptr);  // (else k_fz_stream runs stage 3 itself)
       } else if (n >= 262144) {
         // k_fz_pre (memory-bound) beside the albedo stage (fp64-issue-bound) on a side stream; joined before k_fz_stream
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
         hipLaunchKernelGGL(k_fz_pre, dim3(nblk), dim3(256), 0, side->s[0], S);
         (void)hipEventRecord(side->join[0], side->s[0]);
-        launch_albedo_snicar(S, n, st, side, false);
+        launch_albedo_snicar(S, n, st, side, false, !FZ_ALB_FWD);
         (void)hipStreamWaitEvent(st, side->join[0], 0);
       } else {  // (few columns: the SNICAR queues themselves fork onto the side streams)
         hipLaunchKernelGGL(k_fz_pre, dim3(nblk), dim3(256), 0, st, S);
-        launch_albedo_snicar(S, n, st, side, false);
+        launch_albedo_snicar(S, n, st, side, false, !FZ_ALB_FWD);
       }
       break;
     case 2: hipLaunchKernelGGL(k_fz_stream, dim3(nblk), dim3(256), 0, st, S, dt); break;

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k_surface_radiation(const DevState* __res
 {
   COL_GUARD();
   ColFwd w;
-  surface_radiation_col<false>(S, c, ld, S->land, w);
+  const AlbFwd no_a{};  // (the wrapper's own kernel reads the albedo stage's outputs from the state)
+  const double no_flx[6][4] = {};
+  surface_radiation_col<false>(S, c, ld, S->land, w, no_a, no_flx);
 }
 
 __global__ __launch_bounds__(256) void k_canopy_temperature(const DevState* __restrict__ S)

@@ -477,7 +477,10 @@ __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const Psn
 //                it converges, stores the converged state at the queue position and takes the next position
 //   k_cf_finish  coalesced, one thread per column: compute_flux (:456-540), the 2 m profile, state writes
 // =====================================================================================================
-constexpr int CF_REFILL_MIN = 8;
+#ifndef CF_REFILL_MIN_N
+#define CF_REFILL_MIN_N 8  // (12 / 16 / 24 measured in round 4: profiles/r04_cf_refill_min_ab.txt)
+#endif
+constexpr int CF_REFILL_MIN = CF_REFILL_MIN_N;
 #ifndef CF_PRIO_TRIPS
 #define CF_PRIO_TRIPS 10  // trips after which a column makes its wave a priority wave (k_cf_iterate)
 #endif
@@ -534,13 +537,18 @@ enum : int {
 // Records are stored in blocks of 8 consecutive queue positions: block b holds field k of positions 8b..8b+7 at
 // [b][k][0..7] (64 contiguous bytes), so all fields of neighbouring positions share a few DRAM pages, a refill batch
 // of consecutive positions reads 64-byte runs, and the writers' partial runs merge in L2.
-// CF_REC_AOS / CF_FIN_AOS (development A/B, profiles/r04_record_layout_ab.txt): a record as CF_*_N consecutive doubles at its
-// position - every lane reads or writes ONE contiguous run (16-byte accesses), whatever positions its neighbours hold.
+// CF_REC_AOS / CF_FIN_AOS (profiles/r04_record_layout_ab.txt): a record as CF_*_N consecutive doubles at its position - every
+// lane reads or writes ONE contiguous run (16-byte accesses), whatever positions its neighbours hold.  The FINISH record is
+// written by single lanes as they converge, trips apart from their neighbours: in blocks of 8 positions its 8-byte stores
+// left half-written 64-byte runs behind (PMC: 403 bytes written per column for 192 of payload); per position the kernel writes
+// 199 and the step moves 286 bytes per column less at the same time (k_cf_iterate -0.5 %, k_cf_finish +0.5 %): the product.
+// The INPUT record is written by k_cf_init / k_fz_stream, whose neighbouring threads hold neighbouring positions: per position
+// every wave store would go to 64 different lines (k_cf_init x 2) - it stays in blocks of 8.
 #ifndef CF_REC_AOS
 #define CF_REC_AOS 0
 #endif
 #ifndef CF_FIN_AOS
-#define CF_FIN_AOS 0
+#define CF_FIN_AOS 1
 #endif
 #if CF_REC_AOS
 #define CF_REC_BASE(pos) ((pos) * (int64_t)CF_REC_N)

@@ -141,7 +141,10 @@ __device__ __forceinline__ void st_level_props(const StLevIn& L, const int i, co
 // ground has a second superdiagonal entry (l0, get_matrix_snow_soil) - so that one value stays in a register and the
 // back substitution multiplies by a literal zero elsewhere (the same arithmetic as the reference's 0 * U1 product for
 // every finite solution).  The recurrence itself only needs the last two rows, kept here.
-constexpr int ST_WG = 512;
+#ifndef ST_WG_N
+#define ST_WG_N 512  // (64 / 128 / 192 measured in round 4: profiles/r04_soil_workgroup_ab.txt)
+#endif
+constexpr int ST_WG = ST_WG_N;
 constexpr int ST_LDS_ROWS = NROW - 2;
 typedef double StLds[ST_LDS_ROWS][ST_WG];
 struct StSweep {

@@ -297,10 +297,10 @@ __device__ __forceinline__ AlbIn alb_final_inputs(const DevState* __restrict__ S
     if (h2osno_in > SN_MIN_SNW) {
       const gptr<const double> o = S->alb_snow + c;
       x.snicar = true;
-      x.sd_alb[0] = o[0];
-      x.sd_alb[1] = o[ld];
-      x.si_alb[0] = o[(int64_t)14 * ld];
-      x.si_alb[1] = o[(int64_t)15 * ld];
+      x.sd_alb[0] = sc_ld<1>(o);
+      x.sd_alb[1] = sc_ld<1>(o + ld);
+      x.si_alb[0] = sc_ld<1>(o + (int64_t)14 * ld);
+      x.si_alb[1] = sc_ld<1>(o + (int64_t)15 * ld);
     } else if (h2osno_in < SN_MIN_SNW && h2osno_in > 0.0) {
       // no snow radiative transfer: snow_albedo_radiation_factor's remaining branches (snow_snicar_impl.hh:758-765)
       x.sd_alb[0] = x.si_alb[0] = x.albsoi[0];
@@ -319,10 +319,10 @@ __device__ __forceinline__ void alb_flux_abs_all(const DevState* __restrict__ S,
   for (int i = 0; i < 6; i++) {
     double sdf[2] = {0.0, 0.0}, sif[2] = {0.0, 0.0};
     if (x.snicar) {
-      sdf[0] = o[(int64_t)(2 + 2 * i) * ld];
-      sdf[1] = o[(int64_t)(3 + 2 * i) * ld];
-      sif[0] = o[(int64_t)(16 + 2 * i) * ld];
-      sif[1] = o[(int64_t)(17 + 2 * i) * ld];
+      sdf[0] = sc_ld<1>(o + (int64_t)(2 + 2 * i) * ld);
+      sdf[1] = sc_ld<1>(o + (int64_t)(3 + 2 * i) * ld);
+      sif[0] = sc_ld<1>(o + (int64_t)(16 + 2 * i) * ld);
+      sif[1] = sc_ld<1>(o + (int64_t)(17 + 2 * i) * ld);
     }
     alb_flux_abs_level(L, x.day, x.frac_sno, x.albsod, x.albsoi, x.sd_alb, x.si_alb, sdf, sif, flx[i][0], flx[i][1], flx[i][2], flx[i][3]);
     LV(flx_absdv, i) = flx[i][0];

@@ -142,7 +142,24 @@ template <> struct field_of<ELMK_F64> {
 #else
 typedef double state_real;
 #endif
-typedef field_of<ELMK_F64>::type dfield;  // an fp64 state field (or a position inside one), whatever it is stored as
+typedef field_of<ELMK_F64>::type dfield;
+
+// Scratch streams that one kernel writes once and another reads once: which of their accesses carry the nontemporal hint
+// (ELMK_SCRATCH_NT bit mask; interleaved A/B in profiles/r04_scratch_nt_ab.txt).  1: loads of the SNICAR products (alb_snow),
+// 2: their stores, 4: the canopy queue records.  The records lose badly (their 8-byte stores into blocks of 8 positions
+// depend on merging in L2: k_cf_init +65 %, k_cf_finish +70 %); reading the SNICAR products once, by column, gains.
+#ifndef ELMK_SCRATCH_NT
+#define ELMK_SCRATCH_NT 1
+#endif
+template <int BIT> __device__ __forceinline__ double sc_ld(gptr<const double> p)
+{
+  return ((ELMK_SCRATCH_NT) & BIT) ? __builtin_nontemporal_load(p) : *p;
+}
+template <int BIT> __device__ __forceinline__ void sc_st(gptr<double> p, double v)
+{
+  if ((ELMK_SCRATCH_NT) & BIT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 // indices into one row of the PFT photosynthesis table (member order of ELM::PFTDataPSN, pft_data.h:20-24)
 enum : int {

@@ -365,12 +365,12 @@ __device__ __forceinline__ void snicar_workgroup(const DevState* __restrict__ S,
     snicar_combine<NL>(g0, pass, mu_not, rds_top, albedo, fl, out);
     if (valid && bnd == 0) {
       const gptr<double> o = S->alb_snow + (int64_t)(pass * 14) * ld + c;
-      o[0] = out.alb[0];
-      o[ld] = out.alb[1];
+      sc_st<2>(o, out.alb[0]);
+      sc_st<2>(o + ld, out.alb[1]);
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        o[(int64_t)(2 + 2 * i) * ld] = out.fabs_[i][0];
-        o[(int64_t)(3 + 2 * i) * ld] = out.fabs_[i][1];
+        sc_st<2>(o + (int64_t)(2 + 2 * i) * ld, out.fabs_[i][0]);
+        sc_st<2>(o + (int64_t)(3 + 2 * i) * ld, out.fabs_[i][1]);
       }
     }
     if (valid && err) atomicOr(ELMK_GENERIC(&S->err_flags[c]), err);

@@ -734,7 +734,7 @@ __device__ __forceinline__ void cf_root_stress_col(const DevState* __restrict__ 
     LV(rootr, i) = q;
   }
   S->btran[c] = btran;
-  (S->cf_rec + CF_REC_BASE(pos))[CF_REC_K(REC_btran)] = btran;
+  sc_st<4>(S->cf_rec + CF_REC_BASE(pos) + CF_REC_K(REC_btran), btran);
 }
 
 // ROOT_DONE: the fused step's early kernel (k_fz_pre) has already done cf_root_stress_col and the bare branch's rootr / btran
@@ -761,7 +761,7 @@ __device__ __forceinline__ void cf_init_col(const DevState* __restrict__ S, cons
   // record fields are stored as soon as they are final (PUT), so few of them are live at any time
   CfRec r;
   const gptr<double> rec = S->cf_rec + CF_REC_BASE(pos);
-#define PUT(n) rec[CF_REC_K(REC_##n)] = r.n;
+#define PUT(n) sc_st<4>(rec + CF_REC_K(REC_##n), r.n);
   const int snl = FW(snl, S->snl[c]);
   const int vtype = S->vtype[c];
   const double* __restrict__ P = S->pft_psn[vtype];
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
     if (fresh) {
       fresh = false;
       const gptr<const double> rec = S->cf_rec + CF_REC_BASE(pos);
-#define LD(n) rec[CF_REC_K(REC_##n)]
+#define LD(n) sc_ld<4>(rec + CF_REC_K(REC_##n))
       const gptr<const int32_t> irec = S->cf_irec + pos;
       const int vtype = irec[(int64_t)IREC_vtype * ld];
       nrad = irec[(int64_t)IREC_nrad * ld];
@@ -1386,30 +1386,30 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
       // ---------------- converged: hand the state to k_cf_finish, release the lane ----------------
       if (stop) {
         const gptr<double> fin = S->cf_fin + CF_FIN_BASE(pos);
-        fin[CF_FIN_K(FIN_t_veg)] = t_veg;
-        fin[CF_FIN_K(FIN_btran)] = btran;
-        fin[CF_FIN_K(FIN_qflx_tran_veg)] = qflx_tran_veg;
-        fin[CF_FIN_K(FIN_qflx_evap_veg)] = qflx_evap_veg;
-        fin[CF_FIN_K(FIN_eflx_sh_veg)] = eflx_sh_veg;
-        fin[CF_FIN_K(FIN_wtg)] = wtg;
-        fin[CF_FIN_K(FIN_wtl0)] = wtl0;
-        fin[CF_FIN_K(FIN_wta0)] = wta0;
-        fin[CF_FIN_K(FIN_wtal)] = wtal;
-        fin[CF_FIN_K(FIN_wtgq)] = wtgq;
-        fin[CF_FIN_K(FIN_wtalq)] = wtalq;
-        fin[CF_FIN_K(FIN_wtlq0)] = wtlq0;
-        fin[CF_FIN_K(FIN_wtaq0)] = wtaq0;
-        fin[CF_FIN_K(FIN_delq)] = delq;
-        fin[CF_FIN_K(FIN_qsatl)] = qsatl;
-        fin[CF_FIN_K(FIN_temp1)] = temp1;
-        fin[CF_FIN_K(FIN_temp2)] = temp2;
-        fin[CF_FIN_K(FIN_dth)] = dth;
-        fin[CF_FIN_K(FIN_dqh)] = dqh;
-        fin[CF_FIN_K(FIN_tlbef)] = tlbef;
-        fin[CF_FIN_K(FIN_dt_veg)] = dt_veg;
-        fin[CF_FIN_K(FIN_obu_trip)] = obu_trip;
-        fin[CF_FIN_K(FIN_trips)] = (double)itlef;
-        fin[CF_FIN_K(FIN_err)] = (double)err;
+        sc_st<4>(fin + CF_FIN_K(FIN_t_veg), t_veg);
+        sc_st<4>(fin + CF_FIN_K(FIN_btran), btran);
+        sc_st<4>(fin + CF_FIN_K(FIN_qflx_tran_veg), qflx_tran_veg);
+        sc_st<4>(fin + CF_FIN_K(FIN_qflx_evap_veg), qflx_evap_veg);
+        sc_st<4>(fin + CF_FIN_K(FIN_eflx_sh_veg), eflx_sh_veg);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtg), wtg);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtl0), wtl0);
+        sc_st<4>(fin + CF_FIN_K(FIN_wta0), wta0);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtal), wtal);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtgq), wtgq);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtalq), wtalq);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtlq0), wtlq0);
+        sc_st<4>(fin + CF_FIN_K(FIN_wtaq0), wtaq0);
+        sc_st<4>(fin + CF_FIN_K(FIN_delq), delq);
+        sc_st<4>(fin + CF_FIN_K(FIN_qsatl), qsatl);
+        sc_st<4>(fin + CF_FIN_K(FIN_temp1), temp1);
+        sc_st<4>(fin + CF_FIN_K(FIN_temp2), temp2);
+        sc_st<4>(fin + CF_FIN_K(FIN_dth), dth);
+        sc_st<4>(fin + CF_FIN_K(FIN_dqh), dqh);
+        sc_st<4>(fin + CF_FIN_K(FIN_tlbef), tlbef);
+        sc_st<4>(fin + CF_FIN_K(FIN_dt_veg), dt_veg);
+        sc_st<4>(fin + CF_FIN_K(FIN_obu_trip), obu_trip);
+        sc_st<4>(fin + CF_FIN_K(FIN_trips), (double)itlef);
+        sc_st<4>(fin + CF_FIN_K(FIN_err), (double)err);
         pos = -1;
       }
       PR_T(8)
@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_cf_finish(const DevState* __restrict__ 
   }
   CfFin f;
   const gptr<const double> fin = S->cf_fin + CF_FIN_BASE((int64_t)pos);
-#define X(n) f.n = fin[CF_FIN_K(FIN_##n)];
+#define X(n) f.n = sc_ld<4>(fin + CF_FIN_K(FIN_##n));
   CF_FIN_FIELDS(X)
 #undef X
   const double t_veg = f.t_veg;

@@ -1,13 +1,13 @@
 #!/bin/bash
-# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag> [pmc|bench|rest|all]
+# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag> [pmc|pmc10|bench|rest|all]
 # (outputs under gpurun_out/<tag>/; tests/tools/collect_profiles.sh copies the files to commit into profiles/ with the round
-# prefix.  One gpurun call is limited to 20 minutes, so a round is three calls - pmc, then bench, then rest - with a
+# prefix.  One gpurun call is limited to 20 minutes, so a round is four calls - pmc, pmc10, then bench, then rest - with a
 # collect_profiles.sh after the first: the benchmark reads the PMC tables from profiles/.)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 T=${1:-prof}
 STAGE=${2:-all}
-P=${PROFILE_TAG:-r03}
+P=${PROFILE_TAG:-r04}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -39,6 +39,34 @@ for tier in A B; do
   python3 $R/tests/tools/make_compute_json.py $O/compute_pmc_tier$tier.json 1000000 $tier $O/pmc_lane $O/pmc_f64 | tee $O/compute_pmc_tier$tier.txt
   cp $O/compute_pmc_tier$tier.json $R/profiles/${P}_compute_pmc_tier$tier.json
   rm -rf $O/pmc_lane $O/pmc_f64
+done
+fi
+if [ $STAGE = pmc10 ] || [ $STAGE = all ]; then
+# 1c. the same traffic passes AT THE NORTH-STAR SIZE, 10 M columns (VERDICT r03 missing #4): per-wrapper and fused step, both tiers,
+#     and the fp32-state build's fused step; plus the rocprofv3 kernel statistics of both steps at that size
+for spec in "A timestep7 10M_tierA" "B timestep7 10M_tierB" "A fused 10M_fused_tierA" "B fused 10M_fused_tierB"; do
+  set -- $spec; tier=$1; mode=$2; name=$3
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 10000000 $tier $mode > $O/pmc_fetch_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 10000000 $tier $mode > $O/pmc_write_$name.log 2>&1
+  python3 $R/tests/tools/make_traffic_json.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic_pmc_$name.json 10000000 $tier | tee $O/hbm_traffic_$name.txt
+  cp $O/hbm_traffic_pmc_$name.json $R/profiles/${P}_hbm_traffic_pmc_$name.json
+  rm -rf $O/pmc_fetch $O/pmc_write
+done
+export ELMK_LIBRARY=$R/elmkernels_amd/libelmk_f32.so
+for tier in A B; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 10000000 $tier fused > $O/pmc_fetch_10M_f32_$tier.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py 10000000 $tier fused > $O/pmc_write_10M_f32_$tier.log 2>&1
+  python3 $R/tests/tools/make_traffic_json.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic_pmc_10M_fused_f32_tier$tier.json 10000000 $tier | tee $O/hbm_traffic_10M_fused_f32_tier$tier.txt
+  cp $O/hbm_traffic_pmc_10M_fused_f32_tier$tier.json $R/profiles/${P}_hbm_traffic_pmc_10M_fused_f32_tier$tier.json
+  rm -rf $O/pmc_fetch $O/pmc_write
+done
+unset ELMK_LIBRARY
+for mode in "" "--fused"; do
+  n=bench_10M${mode:+_fused}
+  rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py $mode --cols 10000000 --steps 5 --warmup 2 --no-cpu-baseline --no-other-tier --no-north-star --no-state-f32 > $O/${n}_under_rocprof.json 2> $O/kt10.log
+  cp $O/kt/p_kernel_stats.csv $O/${n}_rocprof_kernel_stats.csv
+  cp $O/${n}_rocprof_kernel_stats.csv $R/profiles/${P}_${n}_rocprof_kernel_stats.csv
+  rm -rf $O/kt
 done
 fi
 if [ $STAGE = bench ] || [ $STAGE = all ]; then

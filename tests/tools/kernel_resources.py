@@ -53,9 +53,16 @@ def main():
 
         doc = {"note": "hipcc --offload-arch=gfx950 metadata of every kernel, product build (fp64 state) and -DELMK_STATE_F32 (fp64 fields stored as "
                        "fp32); waves_per_simd = min(8, 512 / VGPRs, LDS limit)", "source_hash": bench.kernel_source_hash(), "kernels": {}}
+        # the per-translation-unit flags of the product build (FLAGS_<file> in elmkernels_amd/csrc/Makefile: nontemporal state accesses)
+        unit_flags = {}
+        for line in open(os.path.join(CSRC, "Makefile")):
+            m = re.match(r"FLAGS_(\w+)\s*:=\s*(.*)$", line)
+            if m:
+                unit_flags[m.group(1)] = m.group(2).split()
+        doc["unit_flags"] = {k: " ".join(v) for k, v in unit_flags.items()}
         for f in KFILES:
-            a = parse(compile_s(os.path.join(CSRC, f + ".hip")))
-            b = parse(compile_s(os.path.join(CSRC, f + ".hip"), ["-DELMK_STATE_F32"]))
+            a = parse(compile_s(os.path.join(CSRC, f + ".hip"), unit_flags.get(f, [])))
+            b = parse(compile_s(os.path.join(CSRC, f + ".hip"), ["-DELMK_STATE_F32"] + unit_flags.get(f, [])))
             for k in a:
                 doc["kernels"][k] = {"f64_state": a[k], "f32_state": b.get(k)}
         json.dump(doc, open(sys.argv[2], "w"), indent=1)

@@ -18,6 +18,8 @@
 //   * the 30 ViewD1(ncols) temporaries of the wrapper (:11-40) and the 15-level work arrays stay in registers.
 // The arithmetic of each expression (operand order, parenthesisation) is the reference's.
 #define ELMK_MATH_LDS 1  // exp / log / pow tables of elmk_math.h in LDS: every kernel below that evaluates them calls elmk_math_lds_init first
+#include <stdlib.h>
+
 #include "elmk_dev.h"
 #include "elmk_kernels.h"
 #include "elmk_stream.h"
@@ -961,7 +963,10 @@ enum : int {
 #undef X
   CF_NLDS
 };
-constexpr int CF_ITER_THREADS = 512;  // 8 waves = two per SIMD; one workgroup per CU shares one copy of the math tables
+#ifndef CF_ITER_THREADS_N
+#define CF_ITER_THREADS_N 512  // (256: one wave per SIMD, half the LDS - development, tests/tools/two_ctx_overlap.py)
+#endif
+constexpr int CF_ITER_THREADS = CF_ITER_THREADS_N;  // 8 waves = two per SIMD; one workgroup per CU shares one copy of the math tables
 typedef double CfLds[CF_ITER_THREADS];
 #define X(n)                                                                                              \
   __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const CfLds* s, int t) { return R.n; }    \
@@ -1801,6 +1806,19 @@ __global__ __launch_bounds__(256, 3) void k_fz_stream(const DevState* __restrict
 #ifndef FZ_BG_OVERLAP
 #define FZ_BG_OVERLAP 1
 #endif
+// Workgroups of the persistent k_cf_iterate: two per CU are launched (one is resident at its LDS footprint; the ones that start
+// later find the queue empty).  ELMK_CF_GROUPS (development, read once) overrides the 512: a smaller grid leaves CUs to kernels
+// of another context's stream (tests/tools/two_ctx_overlap.py).
+static unsigned cf_iterate_groups(unsigned nblk)
+{
+  static const unsigned cap = [] {
+    const char* e = getenv("ELMK_CF_GROUPS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (unsigned)v : 512u;
+  }();
+  return nblk < cap ? nblk : cap;
+}
+
 void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st, const SideStreams* side, int stage)
 {
   if (n <= 0) return;
@@ -1850,7 +1868,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
       }
       break;
     default: {
-      const unsigned groups = nblk < 512u ? nblk : 512u;
+      const unsigned groups = cf_iterate_groups(nblk);
       hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, 0);
       if (FZ_BG_OVERLAP && n >= 262144) {
         (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
@@ -1871,7 +1889,7 @@ void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t s
   hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S, given);
   // persistent: two waves per SIMD are resident at this kernel's register and LDS footprint (2 workgroups per CU, 512 in
   // all); workgroups that start later find the queue empty
-  unsigned groups = nblk < 512u ? nblk : 512u;
+  const unsigned groups = cf_iterate_groups(nblk);
   hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, given);
   hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt, given);
 }

@@ -211,3 +211,39 @@ def test_parity_bar_is_announced():
     from tests import _parity_mode as M
 
     assert isinstance(M.BITWISE_VALID, bool) and M.REASON
+
+
+def test_bench_cpu_budget_and_floor(tmp_path, monkeypatch):
+    """bench.py's host logic that needs no GPU: the CPU budget honours the affinity mask and the cgroup quota (128 OpenMP
+    threads inside a 16-CPU quota were the 'CPU baseline'), and roofline.floor is formed from the committed counter tables only when
+    they belong to this build and this column count."""
+    import json
+
+    import bench
+
+    cap, info = bench.HOST_CPU_BUDGET
+    assert 1 <= cap <= info["affinity"] and (info["cgroup_quota_cpus"] is None or cap <= max(1, round(info["cgroup_quota_cpus"])))
+    # a traffic table and a compute table of "this build": two kernels, one bandwidth-bound, one arithmetic-bound
+    h = bench.kernel_source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    tag = bench.PROFILE_TAG
+    json.dump({"source_hash": h, "columns": 1_000_000, "kernels": {"elmk::k_a": {"hbm_bytes_per_launch": 5.0e9}, "elmk::k_b": {"hbm_bytes_per_launch": 1.0e9},
+                                                                      "elmk::k_copy": {"hbm_bytes_per_launch": 2.0e9}}},
+              open(prof / f"{tag}_hbm_traffic_pmc_tierA.json", "w"))
+    k = dict(SQ_INSTS_VALU_MUL_F64=0.0, SQ_INSTS_VALU_ADD_F64=0.0, SQ_INSTS_VALU_TRANS_F64=0.0)
+    json.dump({"source_hash": h, "kernels": {"k_a": dict(k, SQ_INSTS_VALU=1.0e6, SQ_INSTS_VALU_FMA_F64=1.0e6),
+                                             "k_b": dict(k, SQ_INSTS_VALU=4.0e8, SQ_INSTS_VALU_FMA_F64=4.0e8)}},
+              open(prof / f"{tag}_compute_pmc_tierA.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: h)
+    fl = bench.step_floor("A", 1_000_000, 2.5, 5000.0)
+    assert fl is not None
+    bytes_ms = 6.0e9 / 5000.0e9 * 1e3                      # 1.2 ms: the calibration copy is not part of the step
+    valu_ms = (1.0e6 + 4.0e8) * 2.2 / 1024 * 1e-6          # 0.86 ms
+    assert abs(fl["bytes_ms"] - bytes_ms) < 1e-3 and abs(fl["valu_ms"] - valu_ms) < 1e-3
+    assert abs(fl["floor_ms"] - max(bytes_ms, valu_ms)) < 1e-3 and abs(fl["frac_of_floor"] - fl["floor_ms"] / 2.5) < 1e-3
+    assert abs(fl["serial_floor_ms"] - (1.0 + 4.0e8 * 2.2 / 1024 * 1e-6)) < 1e-3   # k_a at its byte roof + k_b at its VALU roof
+    assert bench.step_floor("A", 10_000_000, 2.5, 5000.0) is None                  # another column count: no claim
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "another build")
+    assert bench.step_floor("A", 1_000_000, 2.5, 5000.0) is None                   # another build: no claim

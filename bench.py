@@ -629,6 +629,7 @@ def main(argv=None):
     ap.add_argument("--one-gpu-value", type=float, default=None,
                     help="the 1-GPU `value` of the same configuration: with it the line carries scaling_efficiency = value / (N * that)")
     ap.add_argument("--no-soil-10m", action="store_true", help="skip the soil-column solve at 10 M columns (soil_temperature_10M)")
+    ap.add_argument("--no-two-blocks", action="store_true", help="skip the two-block pipeline measurement (two_block_pipeline)")
     ap.add_argument("--no-state-f32", action="store_true", help="skip the compact fp32-state measurement of the default run (fp32_state_10M)")
     ap.add_argument("--state-f32", action="store_true",
                     help="also measure BASELINE config 5's fp32-state variant (libelmk_f32.so: fp64 fields stored as fp32, fp64 arithmetic, "
@@ -643,6 +644,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world  # under a launcher the launcher decides
 
+    # every HIP stream its own hardware queue (the runtime's default is 4 queues shared by all streams of the process): kernels of two
+    # contexts' streams can then be resident together (two_block_pipeline); no effect on the one-context measurements (A/B in
+    # profiles/r04_two_block_overlap.txt).  Read by the runtime when it initialises, hence before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if world == 1 and not args.no_cpu_baseline:
         # the CPU-baseline leg: OpenMP threads bound to neighbouring cores and sleeping between parallel regions instead of
         # spinning on a shared host.  libgomp reads these once, when it is loaded (import torch loads it), hence here.  Not at
@@ -848,6 +853,45 @@ def main(argv=None):
                                "frac": gbs10 / HBM_PEAK_GBS, "bytes_per_column": SOIL_ALGO_BYTES}}
         Ds.close()
 
+    blocks2 = None
+    if solo and not soil and not args.no_two_blocks and args.cols >= 524288 and args.cols <= 4_000_000:
+        # The same columns as TWO blocks - two contexts of cols / 2 on their own streams, the leaf-temperature iteration in
+        # 256-thread workgroups (ELMK_OPT_CF_HALF_WORKGROUPS) so that one block's streaming kernels are resident on the CUs beside the
+        # other block's fp64-bound iteration; fused steps enqueued back to back like the main measurement.  What overlapping the two
+        # halves of the step buys; reported beside `fused_step`, never as `value`.
+        if D is not None:
+            D.close()
+            D = None
+        blocks2 = {"what": "fused step, the columns as two contexts of cols / 2 on two streams, k_cf_iterate in 256-thread workgroups "
+                           "(elmk_set_option ELMK_OPT_CF_HALF_WORKGROUPS); needs GPU_MAX_HW_QUEUES above the runtime's default of 4",
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+        for tier in ("A", "B"):
+            half = args.cols // 2
+            ctxs = [build_state(half, device_index, tier, args.seed + i)[0] for i in range(2)]
+            for Dk in ctxs:
+                Dk.set_option(st.OPT_CF_HALF_WORKGROUPS, 1)
+
+            def both():
+                for Dk in ctxs:
+                    Dk.restore_fields()
+                    st.timestep7_fused(Dk, 1800.0)
+
+            for _ in range(max(args.warmup, 6)):
+                both()
+            for Dk in ctxs:
+                Dk.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                both()
+            for Dk in ctxs:
+                Dk.sync()
+            el = time.perf_counter() - t0
+            for Dk in ctxs:
+                Dk.close()
+            ref = fused_step.get(TIER_NAMES[tier], {}).get("value") if fused_step else None
+            blocks2[TIER_NAMES[tier]] = {"value": 2 * half * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                                         "vs_one_context_fused": None if not ref else 2 * half * args.steps / el / ref}
+
     f32 = None
     if solo and not soil and (args.state_f32 or (not args.no_north_star and not args.no_state_f32 and args.cols < NORTH_STAR_COLS)):
         if D is not None:
@@ -978,6 +1022,8 @@ def main(argv=None):
             out["north_star_10M"] = north
         if soil10 is not None:
             out["soil_temperature_10M"] = soil10
+        if blocks2 is not None:
+            out["two_block_pipeline"] = blocks2
         if f32 is not None:
             out["fp32_state_10M"] = f32
         if not args.no_cpu_baseline and world == 1 and rehearsal is None:  # reported at N = 1 only

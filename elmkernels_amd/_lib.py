@@ -59,6 +59,7 @@ SIGNATURES = {
     "elmk_surface_fluxes": (C.c_int, [_P, C.c_double]),
     "elmk_init_timestep": (C.c_int, [_P]),
     "elmk_set_graph": (C.c_int, [_P, C.c_int]),
+    "elmk_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "elmk_get_forcing": (C.c_int, [_P, _P, _P, C.c_int]),
     "elmk_phenology": (C.c_int, [_P, C.c_double, C.c_double]),
     "elmk_evaluate_conservation": (C.c_int, [_P, C.c_double, _P, _P]),

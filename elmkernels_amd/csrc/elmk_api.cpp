@@ -363,6 +363,25 @@ int elmk_set_graph(elmk_ctx* ctx, int on)
   return ELMK_OK;
 }
 
+int elmk_set_option(elmk_ctx* ctx, int option, int value)
+{
+  if (int rc = enter(ctx)) return rc;
+  if (option != ELMK_OPT_CF_HALF_WORKGROUPS) return invalid(ctx, "elmk_set_option: unknown option");
+  int cus = 0;
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->dev));
+  const int want = value ? (cus > 0 ? cus : 256) : 0;
+  if (want != ctx->side.cf_half_groups) {
+    // a captured graph holds the old launch shape
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (GraphSlot& g : ctx->graph) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+    ctx->side.cf_half_groups = want;
+  }
+  return ELMK_OK;
+}
+
 int elmk_sync(elmk_ctx* ctx)
 {
   if (int rc = enter(ctx)) return rc;
@@ -743,7 +762,7 @@ int elmk_bareground_fluxes(elmk_ctx* ctx)
 int elmk_canopy_fluxes(elmk_ctx* ctx, double dt)
 {
   PHYSICS_PROLOGUE();
-  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream);
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream, 0, &ctx->side);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }
@@ -771,7 +790,7 @@ int elmk_canopy_fluxes_given(elmk_ctx* ctx, double dt, const double* forc_rho, c
   PHYSICS_PROLOGUE();
   int mask = 0;
   if (int rc = stage_given(ctx, forc_rho, forc_po2, forc_pco2, &mask)) return rc;
-  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream, mask);
+  launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream, mask, &ctx->side);
   HIPCHK(hipGetLastError());
   return ELMK_OK;
 }
@@ -916,7 +935,7 @@ void launch_stage7(elmk_ctx* ctx, int k, double dt)
     case 3: launch_surface_radiation(ctx->d, ctx->ncols, ctx->stream); break;
     case 4: launch_canopy_temperature(ctx->d, ctx->ncols, ctx->stream); break;
     case 5: launch_bareground_fluxes(ctx->d, ctx->ncols, ctx->stream); break;
-    default: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream); break;
+    default: launch_canopy_fluxes(ctx->d, ctx->ncols, dt, ctx->stream, 0, &ctx->side); break;
   }
 }
 // elmk_timestep7_fused: the same seven wrappers as ELMK_FUSED_NSTAGE launch groups (k_canopy_fluxes.hip)

@@ -17,6 +17,9 @@ struct SideStreams {
   hipStream_t s[ELMK_NSIDE];
   hipEvent_t fork;
   hipEvent_t join[ELMK_NSIDE];
+  // launch shape of the leaf-temperature iteration (elmk_set_option ELMK_OPT_CF_HALF_WORKGROUPS): > 0 = k_cf_iterate_half with at most
+  // this many 256-thread workgroups (the device's CU count: one per CU), 0 = the product's k_cf_iterate
+  int cf_half_groups;
 };
 
 // the seven physics launches (one per reference L3 wrapper)
@@ -30,7 +33,7 @@ void launch_surface_radiation(const DevState* S, int64_t n, hipStream_t st);
 void launch_canopy_temperature(const DevState* S, int64_t n, hipStream_t st);
 // given (bit 0 forc_rho, bit 1 forc_po2, bit 2 forc_pco2): the L2-level entries elmk_*_given take these from DevState::cf_given
 void launch_bareground_fluxes(const DevState* S, int64_t n, hipStream_t st, int given = 0);
-void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given = 0);
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given = 0, const SideStreams* side = nullptr);
 // elmk_timestep7_fused: the same seven wrappers as five launch groups (k_canopy_fluxes.hip):
 //   0 k_fz_prep (frac_wet, list resets, canopy_fluxes class count)   1 albedo_snicar   2 k_fz_stream (canopy_hydrology ->
 //   surface_radiation -> canopy_temperature -> bare-ground list -> canopy_fluxes initialize_flux, one pass per column)

@@ -967,24 +967,26 @@ enum : int {
 #define CF_ITER_THREADS_N 512  // (256: one wave per SIMD, half the LDS - development, tests/tools/two_ctx_overlap.py)
 #endif
 constexpr int CF_ITER_THREADS = CF_ITER_THREADS_N;  // 8 waves = two per SIMD; one workgroup per CU shares one copy of the math tables
-typedef double CfLds[CF_ITER_THREADS];
+constexpr int CF_ITER_THREADS_HALF = 256;           // k_cf_iterate_half: one wave per SIMD, 92 KB of LDS - room for other kernels beside it
 #define X(n)                                                                                              \
-  __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const CfLds* s, int t) { return R.n; }    \
-  __device__ __forceinline__ void cf_set_##n(CfRegs& R, CfLds* s, int t, double v) { R.n = v; }
+  template <class L> __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const L* s, int t) { return R.n; } \
+  template <class L> __device__ __forceinline__ void cf_set_##n(CfRegs& R, L* s, int t, double v) { R.n = v; }
 CF_REG_FIELDS(X)
 #undef X
 #define X(n)                                                                                                       \
-  __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const CfLds* s, int t) { return s[CL_##n][t]; }    \
-  __device__ __forceinline__ void cf_set_##n(CfRegs& R, CfLds* s, int t, double v) { s[CL_##n][t] = v; }
+  template <class L> __device__ __forceinline__ double cf_get_##n(const CfRegs& R, const L* s, int t) { return s[CL_##n][t]; } \
+  template <class L> __device__ __forceinline__ void cf_set_##n(CfRegs& R, L* s, int t, double v) { s[CL_##n][t] = v; }
 CF_LDS_FIELDS(X)
 #undef X
 #define C(n) cf_get_##n(R, s_col, tid)
 #define CSET(n, v) cf_set_##n(R, s_col, tid, (v))
 
-__global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevState* __restrict__ S, double dtime, const int given)
+// (the body as a template over the workgroup size: the per-lane LDS slots are [field][thread of the workgroup])
+template <int THREADS>
+__device__ __forceinline__ void cf_iterate_body(const DevState* __restrict__ S, double dtime, const int given)
 {
   elmk_math_lds_init<true>();
-  __shared__ CfLds s_col[CF_NLDS];
+  __shared__ double s_col[CF_NLDS][THREADS];
   __shared__ double s_pft[ELMK_MXPFT * PFT_STRIDE];
   __shared__ FvConst s_fv;  // (in LDS, not in registers: kernel-lifetime constants would be the first thing spilled)
   if (threadIdx.x < ELMK_MXPFT) cf_pft_row(S, threadIdx.x, s_pft + threadIdx.x * PFT_STRIDE);
@@ -1020,7 +1022,7 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
   uint64_t pr_texh = 0, pr_trips = 0, pr_lanes = 0, pr_refills = 0, pr_cols = 0, pr_brent = 0, pr_brent_trips = 0, pr_c4 = 0, pr_day = 0;
 #endif
 #if CF_PROBE >= 4
-  __shared__ uint32_t s_wev[2][CF_ITER_THREADS / 64];  // wave-level ci_func executions, [phase][wave]
+  __shared__ uint32_t s_wev[2][THREADS / 64];  // wave-level ci_func executions, [phase][wave]
   if (lane == 0) s_wev[0][threadIdx.x >> 6] = s_wev[1][threadIdx.x >> 6] = 0u;
   uint32_t pr_nev_sun = 0u, pr_nev_sha = 0u;  // per-lane ci_func evaluations
   uint64_t pr_daytrips = 0;                   // wave-trips with at least one day lane
@@ -1456,6 +1458,19 @@ __global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevStat
 }
 #undef C
 #undef CSET
+__global__ __launch_bounds__(CF_ITER_THREADS, 2) void k_cf_iterate(const DevState* __restrict__ S, double dtime, const int given)
+{
+  cf_iterate_body<CF_ITER_THREADS>(S, dtime, given);
+}
+// The same iteration in 256-thread workgroups: one wave per SIMD and 92 KB of LDS, one workgroup per CU - slower on its own (the
+// second wave per SIMD is what fills the fp64 pipe, 1.29 against 0.87 ms per million columns) but it leaves half the register file
+// and 68 KB of LDS to the workgroups of OTHER kernels, which are then resident on the same CUs: the launch shape for a block of columns
+// whose iteration runs beside another block's streaming kernels (elmk_set_option ELMK_OPT_CF_HALF_WORKGROUPS,
+// profiles/r04_two_block_overlap.txt).
+__global__ __launch_bounds__(CF_ITER_THREADS_HALF, 2) void k_cf_iterate_half(const DevState* __restrict__ S, double dtime, const int given)
+{
+  cf_iterate_body<CF_ITER_THREADS_HALF>(S, dtime, given);
+}
 
 // =====================================================================================================
 // k_cf_finish - one thread per column, coalesced: compute_flux (canopy_fluxes_impl.hh:456-540) from the converged
@@ -1819,6 +1834,16 @@ static unsigned cf_iterate_groups(unsigned nblk)
   return nblk < cap ? nblk : cap;
 }
 
+static void launch_cf_iterate(const DevState* S, unsigned nblk, double dt, hipStream_t st, const SideStreams* side, int given)
+{
+  if (side && side->cf_half_groups > 0) {  // (one workgroup per CU and no more: what is launched is resident)
+    const unsigned g = nblk * 256u / CF_ITER_THREADS_HALF < (unsigned)side->cf_half_groups ? nblk * 256u / CF_ITER_THREADS_HALF : (unsigned)side->cf_half_groups;
+    hipLaunchKernelGGL(k_cf_iterate_half, dim3(g ? g : 1u), dim3(CF_ITER_THREADS_HALF), 0, st, S, dt, given);
+    return;
+  }
+  hipLaunchKernelGGL(k_cf_iterate, dim3(cf_iterate_groups(nblk)), dim3(CF_ITER_THREADS), 0, st, S, dt, given);
+}
+
 void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st, const SideStreams* side, int stage)
 {
   if (n <= 0) return;
@@ -1868,8 +1893,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
       }
       break;
     default: {
-      const unsigned groups = cf_iterate_groups(nblk);
-      hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, 0);
+      launch_cf_iterate(S, nblk, dt, st, side, 0);
       if (FZ_BG_OVERLAP && n >= 262144) {
         (void)hipStreamWaitEvent(side->s[0], side->fork, 0);
         launch_bareground_list(S, n, side->s[0]);
@@ -1881,7 +1905,7 @@ void launch_fused_stage(const DevState* S, int64_t n, double dt, hipStream_t st,
   }
 }
 
-void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given)
+void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t st, int given, const SideStreams* side)
 {
   if (n <= 0) return;
   const unsigned nblk = (unsigned)((n + 255) / 256);
@@ -1889,8 +1913,7 @@ void launch_canopy_fluxes(const DevState* S, int64_t n, double dt, hipStream_t s
   hipLaunchKernelGGL(k_cf_init, dim3(nblk), dim3(256), 0, st, S, given);
   // persistent: two waves per SIMD are resident at this kernel's register and LDS footprint (2 workgroups per CU, 512 in
   // all); workgroups that start later find the queue empty
-  const unsigned groups = cf_iterate_groups(nblk);
-  hipLaunchKernelGGL(k_cf_iterate, dim3(groups), dim3(CF_ITER_THREADS), 0, st, S, dt, given);
+  launch_cf_iterate(S, nblk, dt, st, side, given);
   hipLaunchKernelGGL(k_cf_finish, dim3(nblk), dim3(256), 0, st, S, dt, given);
 }
 

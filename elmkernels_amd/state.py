@@ -17,6 +17,7 @@ from . import _lib as L
 
 DTYPES = {0: np.float64, 1: np.int32, 2: np.uint8, 3: np.uint32}
 LAYOUT_COL_MAJOR, LAYOUT_SOA = 0, 1
+OPT_CF_HALF_WORKGROUPS = 1  # elmk_set_option
 
 # member order of ELM::PFTDataPSN (src/data/pft_data.h:20-24)
 PSN_FIELDS = (
@@ -255,6 +256,10 @@ class ELMState:
         ms = C.c_float()
         self._chk(self.lib.elmk_profile_wrapper(self.ctx, int(wrapper), float(dt), int(nsteps), C.byref(ms)), "profile_wrapper")
         return ms.value
+
+    def set_option(self, option, value):
+        """Launch options (elmk_set_option); OPT_CF_HALF_WORKGROUPS: the leaf-temperature iteration in 256-thread workgroups, one per CU."""
+        self._chk(self.lib.elmk_set_option(self.ctx, int(option), int(value)), "set_option")
 
     def set_graph(self, on=True):
         """timestep7 as one replayed HIP graph (elmk_set_graph)."""

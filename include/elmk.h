@@ -163,6 +163,14 @@ int elmk_sync(elmk_ctx *ctx);
  * a HIP graph and replays it on every call with the same dt and stream.  Same kernels, same order, same results; what
  * it removes is per-launch host latency, which is all there is to a step of a few thousand columns. */
 int elmk_set_graph(elmk_ctx *ctx, int on);
+/* Launch options of a context (no effect on results, bit for bit).
+ *   ELMK_OPT_CF_HALF_WORKGROUPS  value != 0: the leaf-temperature iteration of kokkos_canopy_fluxes (k_cf_iterate) runs in 256-thread
+ *     workgroups, one per compute unit - half the registers and 68 KB of a CU's LDS stay free, so the kernels of ANOTHER context's
+ *     stream are resident on the same CUs and use the memory pipeline this fp64-bound kernel leaves idle.  For a driver that steps two
+ *     (or more) blocks of columns as separate contexts on separate streams; on its
+ *     own the kernel is 1.5 x slower in this shape, which is why it is an option. */
+enum { ELMK_OPT_CF_HALF_WORKGROUPS = 1 };
+int elmk_set_option(elmk_ctx *ctx, int option, int value);
 int64_t elmk_ncols(const elmk_ctx *ctx);
 int64_t elmk_level_stride(const elmk_ctx *ctx); /* elements between consecutive levels of a device field */
 int64_t elmk_device_bytes(const elmk_ctx *ctx);

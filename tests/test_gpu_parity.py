@@ -1112,6 +1112,33 @@ def test_fused_timestep_large_launch_structure(tier, n, seed):
     Fz.close()
 
 
+@pytest.mark.parametrize("tier,n,seed", [("B", 20000, 101), ("B", 300_000, 102)])
+def test_half_workgroup_iteration_is_the_same_step(tier, n, seed):
+    """elmk_set_option(ELMK_OPT_CF_HALF_WORKGROUPS): the leaf-temperature iteration in 256-thread workgroups, one per CU (the launch shape
+    for a block of columns that runs beside another context's kernels) is the same kernel body on another workgroup size: fused and per
+    wrapper, bit-identical in every field to the product's shape and to the oracle, trip counts included; switching back works."""
+    ft = st.field_table()
+    cols, scal, soil = synth.make_state(ft, n, tier=tier, seed=seed)
+    U = H.device_state(cols, scal, soil)
+    Hf = H.device_state(cols, scal, soil)
+    S = H.oracle_state(cols, scal, soil)
+    Hf.set_option(st.OPT_CF_HALF_WORKGROUPS, 1)
+    for step in range(3):
+        st.timestep7_fused(U, DT)
+        if step == 1:
+            st.timestep7(Hf, DT)          # the per-wrapper canopy_fluxes takes the option too
+        else:
+            st.timestep7_fused(Hf, DT)
+        S.timestep7(DT)
+        _same_bits(U, Hf, f"half workgroups, {tier}/{n}/step {step}")
+        _check(Hf, S, f"half workgroups vs oracle, {tier}/{n}/step {step}", bitwise=True)
+        assert np.array_equal(U.canopy_trip_counts(), Hf.canopy_trip_counts())
+        if step == 1:
+            Hf.set_option(st.OPT_CF_HALF_WORKGROUPS, 0)
+    U.close()
+    Hf.close()
+
+
 def test_fused_timestep_other_land_units_and_graph():
     """The fused step on the land units that take the short branches (wetland, land ice, lake, urban), mixed with unfused
     steps on the same context (the two launch structures share the queue scratch), and replayed as a HIP graph."""

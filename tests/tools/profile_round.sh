@@ -63,7 +63,7 @@ done
 unset ELMK_LIBRARY
 for mode in "" "--fused"; do
   n=bench_10M${mode:+_fused}
-  rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py $mode --cols 10000000 --steps 5 --warmup 2 --no-cpu-baseline --no-other-tier --no-north-star --no-state-f32 > $O/${n}_under_rocprof.json 2> $O/kt10.log
+  rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py $mode --cols 10000000 --steps 5 --warmup 2 --no-cpu-baseline --no-other-tier --no-north-star --no-state-f32 --no-two-blocks > $O/${n}_under_rocprof.json 2> $O/kt10.log
   cp $O/kt/p_kernel_stats.csv $O/${n}_rocprof_kernel_stats.csv
   cp $O/${n}_rocprof_kernel_stats.csv $R/profiles/${P}_${n}_rocprof_kernel_stats.csv
   rm -rf $O/kt
@@ -74,10 +74,10 @@ if [ $STAGE = bench ] || [ $STAGE = all ]; then
 cd $R
 python3 bench.py --state-f32 > $O/bench_1M.json 2> $O/bench_1M.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-tier --no-north-star > $O/bench_1M_under_rocprof.json 2> $O/kt.log
+rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-tier --no-north-star --no-two-blocks > $O/bench_1M_under_rocprof.json 2> $O/kt.log
 cp $O/kt/p_kernel_stats.csv $O/bench_1M_rocprof_kernel_stats.csv
 rm -rf $O/kt
-rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --fused --no-cpu-baseline --no-other-tier --no-north-star > $O/bench_1M_fused_under_rocprof.json 2> $O/ktf.log
+rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --fused --no-cpu-baseline --no-other-tier --no-north-star --no-two-blocks > $O/bench_1M_fused_under_rocprof.json 2> $O/ktf.log
 cp $O/kt/p_kernel_stats.csv $O/bench_1M_fused_rocprof_kernel_stats.csv
 rm -rf $O/kt
 for f in bench_1M.json bench_1M_rocprof_kernel_stats.csv bench_1M_fused_rocprof_kernel_stats.csv; do cp $O/$f $R/profiles/${P}_$f; done

@@ -139,6 +139,8 @@ template <> struct field_of<ELMK_F64> {
   using type = NTField;
   static __host__ __device__ type from(void* p) { return NTField{(gptr<double>)p}; }
 };
+static_assert(sizeof(NTField) == sizeof(gptr<double>) && alignof(NTField) == alignof(gptr<double>),
+              "NTField must have the layout of the plain field pointer: DevState is shared by units built with and without the hint");
 #else
 typedef double state_real;
 #endif

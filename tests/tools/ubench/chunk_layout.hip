@@ -56,13 +56,16 @@ void run(double* a, int64_t n, int64_t ch)
   fflush(stdout);
 }
 
+// odd = false: chunk sizes that are powers of two; odd = true: + 64 columns each (a row stride of exactly 32 KB could alias HBM channels)
 template <int K, int G>
-void sweep(double* a, int64_t n)
+void sweep(double* a, int64_t n, bool odd)
 {
-  const int64_t chs[] = {n, 65536, 16384, 4096, 1024, 256, 64};
+  const int64_t o = odd ? 64 : 0;
+  const int64_t chs[] = {n, 65536 + o, 16384 + o, 4096 + o, 1024 + o, 256 + o, odd ? 4096 : 64};
   for (int64_t ch : chs) run<K, G, false>(a, n, ch);
   run<K, G, true>(a, n, n);
-  run<K, G, true>(a, n, 4096);
+  run<K, G, true>(a, n, 4096 + o);
+  if (odd) run<K, G, true>(a, n, 16384 + o);
 }
 
 int main(int argc, char** argv)
@@ -72,10 +75,17 @@ int main(int argc, char** argv)
   double* a;
   if (hipMalloc(&a, (size_t)2 * KMAX * nmax * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
   (void)hipMemset(a, 0, (size_t)2 * KMAX * nmax * 8);
+  if (argc > 1) {  // ./chunk_layout odd: the product's column counts, chunk sizes that are not powers of two
+    for (int64_t n : {(int64_t)1000000, (int64_t)10000000}) {
+      sweep<128, 8>(a, n, true);
+      sweep<128, 32>(a, n, true);
+    }
+    return 0;
+  }
   for (int64_t n : {(int64_t)1 << 20, nmax}) {
-    sweep<64, 8>(a, n);
-    sweep<128, 8>(a, n);
-    sweep<128, 32>(a, n);
+    sweep<64, 8>(a, n, false);
+    sweep<128, 8>(a, n, false);
+    sweep<128, 32>(a, n, false);
   }
   return 0;
 }

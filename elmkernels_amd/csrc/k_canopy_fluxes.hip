@@ -464,6 +464,48 @@ __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const Psn
   return 0.0;
 }
 
+// photosynthesis() of a phase without light (par_z <= 0, :161-173) or without a canopy layer: psn_phase_solve's branch of that
+// case on its own - the same operations - for the lanes whose column has no light in EITHER phase (they run no root find)
+__device__ __forceinline__ double psn_phase_dark(const PsnSolveIn& I, int nrad, double rb, double btran, double lai_z)
+{
+  if (nrad <= 0) return 0.0;  // laican == 0 -> rs = 0 (:266-281)
+  const double bbb = dmax(I.bbbopt * btran, 1.0);
+  const double rsmax0 = 2.0e4;
+  const double rs_z = dmin(rsmax0, 1.0 / bbb * I.cf);
+  double laican = 0.0, gscan = 0.0;
+  gscan += lai_z / (rb + rs_z);
+  laican += lai_z;
+  if (laican > 0.0) return laican / gscan - rb;
+  return 0.0;
+}
+
+// lane index of the r-th (0-based) set bit of a wave-uniform mask; r < popcount(m)
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r)
+{
+  uint32_t w = (uint32_t)m;
+  int idx = 0;
+  int c = __popc(w);
+  if (r >= c) {
+    r -= c;
+    w = (uint32_t)(m >> 32);
+    idx = 32;
+  }
+#pragma unroll
+  for (int width = 16; width >= 1; width >>= 1) {
+    const uint32_t lowmask = (1u << width) - 1u;
+    c = __popc(w & lowmask);
+    if (r >= c) {
+      r -= c;
+      w >>= width;
+      idx += width;
+    }
+    w &= lowmask;
+  }
+  return idx;
+}
+#ifndef CF_PAIR_PHASES
+#define CF_PAIR_PHASES 1  // 0: every lane runs both solves of its column itself, whatever the wave holds (development A/B)
+#endif
 
 // =====================================================================================================
 // Launch structure.  The leaf-temperature iteration has data-dependent trip counts (3..41) and is fp64-compute
@@ -483,6 +525,9 @@ __device__ __forceinline__ double psn_phase_solve(const PsnSolveIn& I, const Psn
 #define CF_REFILL_MIN_N 8  // (12 / 16 / 24 measured in round 4: profiles/r04_cf_refill_min_ab.txt)
 #endif
 constexpr int CF_REFILL_MIN = CF_REFILL_MIN_N;
+#ifndef CF_PRIO_LEVEL
+#define CF_PRIO_LEVEL 2  // s_setprio of a wave that carries a column past CF_PRIO_TRIPS trips (3 measured: profiles/r04_cf_phase_pairing_ab.txt)
+#endif
 #ifndef CF_PRIO_TRIPS
 #define CF_PRIO_TRIPS 10  // trips after which a column makes its wave a priority wave (k_cf_iterate)
 #endif
@@ -1167,16 +1212,28 @@ __device__ __forceinline__ void cf_iterate_body(const DevState* __restrict__ S, 
     // 41-trip limit, and often Brent's method in every trip: a millisecond of dependent work on their own): it gets issue
     // priority over the wave it shares the SIMD with, which then fills the gaps instead of competing for the slots.
     if (__ballot(pos >= 0 && itlef >= CF_PRIO_TRIPS) != 0ull) {
-      __builtin_amdgcn_s_setprio(2);
+      __builtin_amdgcn_s_setprio(CF_PRIO_LEVEL);
     } else {
       __builtin_amdgcn_s_setprio(0);
     }
 
     // ---------------- one trip of the leaf-temperature iteration (:233-450) ----------------
+    // The trip is in three parts: up to the inputs of the two photosynthesis root finds (lanes with a column), the root finds
+    // (below: ALL lanes of the wave may take part), the energy balance and the stop test (lanes with a column).  What crosses
+    // the parts is declared here.
+    double ustar = 0.0, temp1 = 0.0, temp2 = 0.0, obu_trip = 0.0, zldis = 0.0, tlbef = 0.0, del2 = 0.0, rah0 = 0.0, raw0 = 0.0,
+           uaf = 0.0, rb = 0.0, rah1 = 0.0, raw1 = 0.0, svpts = 0.0, eah = 0.0;
+    PsnPhaseIn qsun, qsha;
+    qsun.lmr_z = qsun.vcmax_z = qsun.jmax_z = qsun.tpu_z = qsun.kp_z = 0.0;
+    qsha = qsun;
+    PsnSolveIn J;
+    J.c3flag = true;
+    J.cf = J.qe = J.theta_cj = J.bbbopt = J.mbbopt = J.cp = J.kc = J.ko = 0.0;
+    double btran_sun = 0.0, btran_sha = 0.0, forc_po2 = 0.0, forc_pco2 = 0.0;
     if (pos >= 0) {
-      double ustar, temp1, temp2, unused12m = 0.0, unused22m = 0.0;
-      const double obu_trip = obu;
-      const double zldis = C(zl_u);
+      double unused12m = 0.0, unused22m = 0.0;
+      obu_trip = obu;
+      zldis = C(zl_u);
       // the 2 m profiles (:239-240) are only read by compute_flux: k_cf_finish evaluates them from obu_trip
       {
         const double z0mv = C(z0mv);
@@ -1184,15 +1241,14 @@ __device__ __forceinline__ void cf_iterate_body(const DevState* __restrict__ S, 
                                           unused12m, unused22m);
       }
       PR_T(1)
-      const double tlbef = t_veg;
-      const double del2 = del;
+      tlbef = t_veg;
+      del2 = del;
       const double ram = 1.0 / (ustar * ustar / um);
-      const double rah0 = 1.0 / (temp1 * ustar);
-      const double raw0 = 1.0 / (temp2 * ustar);
-      const double uaf = um * sqrt(1.0 / (ram * um));
+      rah0 = 1.0 / (temp1 * ustar);
+      raw0 = 1.0 / (temp2 * ustar);
+      uaf = um * sqrt(1.0 / (ram * um));
       const double cf = 0.01 / (sqrt(uaf) * PR[PFT_sqrt_dleaf]);
-      const double rb = 1.0 / (cf * uaf);
-      double rah1;
+      rb = 1.0 / (cf * uaf);
       {
         const double w = C(w_lai);
         const double csoilb = (VKC / (0.13 * elmk_pow((C(z0mg) * uaf / 1.5e-5), 0.45)));
@@ -1206,16 +1262,12 @@ __device__ __forceinline__ void cf_iterate_body(const DevState* __restrict__ S, 
         }
         rah1 = 1.0 / (csoilcn * uaf);
       }
-      const double raw1 = rah1;
-      const double svpts = el;
-      const double eah = C(forc_pbot) * qaf / 0.622;
+      raw1 = rah1;
+      svpts = el;
+      eah = C(forc_pbot) * qaf / 0.622;
       PR_T(2)
 
-      double rssun, rssha;
       {
-        PsnPhaseIn qsun, qsha;
-        PsnSolveIn J;
-        double btran_sun, btran_sha;
         {
           // temperature factors of this trip, shared by both phases; consumed here for both
           const double tc = C(tc10);
@@ -1244,19 +1296,107 @@ __device__ __forceinline__ void cf_iterate_body(const DevState* __restrict__ S, 
         J.theta_cj = PR[PFT_theta_cj];
         J.bbbopt = PR[PFT_bbbopt];
         J.mbbopt = PR[PFT_mbbopt];
-        double forc_po2 = derive_forc_po2(C(forc_pbot)), forc_pco2 = derive_forc_pco2(C(forc_pbot));
+        forc_po2 = derive_forc_po2(C(forc_pbot));
+        forc_pco2 = derive_forc_pco2(C(forc_pbot));
         if (given & 6) {  // (L2-level entry only: the column's own values, kept in its queue record)
           const gptr<const double> grec = S->cf_rec + CF_REC_BASE(pos);
           forc_po2 = grec[CF_REC_K(REC_forc_po2)];
           forc_pco2 = grec[CF_REC_K(REC_forc_pco2)];
         }
-        PR_T(3)
-        rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun),
-                                C(lai_sun_z), err PR_SOLVE_ARGS(0, pr_nev_sun));
-        PR_T(4)
-        rssha = psn_phase_solve(J, qsha, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sha, C(parsha),
-                                C(lai_sha_z), err PR_SOLVE_ARGS(1, pr_nev_sha));
       }
+      PR_T(3)
+    }
+
+    // ---------------- the two photosynthesis root finds of the trip (photosynthesis_impl.hh:9-283, called at :296 and :316) ----------------
+    // The sunlit and the shaded solve of a column are independent and run one after the other on its lane.  A column that does not
+    // converge takes 41 trips of ~20-30 us each (Brent's method in both phases of every trip) whatever the rest of the machine does,
+    // and at a million columns that one serial chain IS the kernel's duration: 41-trip columns started at time zero end when the kernel
+    // ends.  So whenever a wave holds no more day lanes than other lanes - the tail, and the passage from day to night columns -
+    // every day lane borrows one of the others: the HELPER takes the shaded phase's inputs by shuffle, both lanes run the one solve
+    // side by side, and the owner takes the result back.  Same function, same operands, another lane: the bits do not change.
+    double rssun = 0.0, rssha = 0.0;
+    {
+      const bool has = pos >= 0;
+      const bool dayl = has && day;
+#if CF_PROBE >= 4
+      if (has) {
+        rssun = psn_phase_solve(J, qsun, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sun, C(parsun), C(lai_sun_z), err PR_SOLVE_ARGS(0, pr_nev_sun));
+        PR_T(4)
+        rssha = psn_phase_solve(J, qsha, nrad, C(forc_pbot), svpts, eah, forc_po2, forc_pco2, rb, btran_sha, C(parsha), C(lai_sha_z), err PR_SOLVE_ARGS(1, pr_nev_sha));
+      }
+#else
+      if (has && !day) {  // no light in either phase (or no canopy layer): no root find (:161-173)
+        rssun = psn_phase_dark(J, nrad, rb, btran_sun, C(lai_sun_z));
+        rssha = psn_phase_dark(J, nrad, rb, btran_sha, C(lai_sha_z));
+      }
+      const unsigned long long md = __ballot(dayl);
+      const int nd = __popcll(md);
+      if (nd != 0) {  // (wave-uniform)
+        const bool paired = CF_PAIR_PHASES && nd <= 32;
+        // what the solve reads beside J / qsun, as this lane will hand it in: its own sunlit phase first
+        double pb = has ? C(forc_pbot) : 0.0, rbi = rb, bt = btran_sun;
+        double par = has ? C(parsun) : 0.0, lai = has ? C(lai_sun_z) : 0.0;
+        int nr = nrad;
+        int helper_of = lane;
+        bool is_helper = false;
+        if (paired) {
+          // the r-th day lane pairs with the r-th lane that is not a day lane (there are at least as many)
+          const int rd = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+          const int rn = lane - rd;  // rank among the lanes that are not day lanes
+          is_helper = !dayl && rn < nd;
+          if (dayl) helper_of = nth_set_bit(~md, rd);
+          const int src = is_helper ? nth_set_bit(md, rn) : lane;
+          // Every lane takes part in the shuffles; only the helpers keep what they pull - the SHADED inputs of their owner - and
+          // they keep it in the slots of their own sunlit inputs, which are dead by now (a helper's own column has no light: its
+          // two results were formed above; rb and nrad, which its own trip still reads, go to copies).
+          const double par_h = has ? C(parsha) : 0.0, lai_h = has ? C(lai_sha_z) : 0.0;
+#define PULL(dst, own_shaded)                             \
+  {                                                       \
+    const double t_ = __shfl((own_shaded), src, 64);      \
+    if (is_helper) dst = t_;                              \
+  }
+          PULL(qsun.lmr_z, qsha.lmr_z) PULL(qsun.vcmax_z, qsha.vcmax_z) PULL(qsun.jmax_z, qsha.jmax_z) PULL(qsun.tpu_z, qsha.tpu_z)
+          PULL(qsun.kp_z, qsha.kp_z) PULL(bt, btran_sha) PULL(par, par_h) PULL(lai, lai_h)
+          PULL(pb, pb) PULL(svpts, svpts) PULL(eah, eah) PULL(forc_po2, forc_po2) PULL(forc_pco2, forc_pco2) PULL(rbi, rb)
+          PULL(J.cf, J.cf) PULL(J.qe, J.qe) PULL(J.theta_cj, J.theta_cj) PULL(J.bbbopt, J.bbbopt) PULL(J.mbbopt, J.mbbopt)
+          PULL(J.cp, J.cp) PULL(J.kc, J.kc) PULL(J.ko, J.ko)
+#undef PULL
+          const int packed = __shfl((nrad << 1) | (J.c3flag ? 1 : 0), src, 64);
+          if (is_helper) {
+            nr = packed >> 1;
+            J.c3flag = (packed & 1) != 0;
+          }
+        }
+        const int nph = paired ? 1 : 2;
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ph++) {  // ONE instance of the solve in the code: unpaired, the shaded phase is its second pass
+          if (ph == 1) {
+            qsun = qsha;
+            bt = btran_sha;
+            par = has ? C(parsha) : 0.0;
+            lai = has ? C(lai_sha_z) : 0.0;
+          }
+          double r = 0.0;
+          uint32_t e = 0u;
+          if (dayl || is_helper) r = psn_phase_solve(J, qsun, nr, pb, svpts, eah, forc_po2, forc_pco2, rbi, bt, par, lai, e);
+          if (paired) {  // the owner takes the shaded result and its flags back from its helper
+            const double rh = __shfl(r, helper_of, 64);
+            const uint32_t eh = (uint32_t)__shfl((int)e, helper_of, 64);
+            if (dayl) {
+              rssun = r;
+              rssha = rh;
+              err |= e | eh;
+            }
+          } else if (dayl) {
+            if (ph == 0) rssun = r;
+            else rssha = r;
+            err |= e;
+          }
+        }
+      }
+#endif
+    }
+    if (pos >= 0) {
       PR_T(5)
 #if CF_PROBE >= 4
       pr_brent += (uint64_t)__popcll(__ballot((err & 0x80000000u) != 0u));

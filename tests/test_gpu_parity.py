@@ -1135,6 +1135,15 @@ def test_half_workgroup_iteration_is_the_same_step(tier, n, seed):
         assert np.array_equal(U.canopy_trip_counts(), Hf.canopy_trip_counts())
         if step == 1:
             Hf.set_option(st.OPT_CF_HALF_WORKGROUPS, 0)
+    # an unknown option is refused (and changes nothing); the option also holds under graph replay
+    assert Hf.lib.elmk_set_option(Hf.ctx, 99, 1) < 0
+    if n <= 20000:
+        Hf.set_option(st.OPT_CF_HALF_WORKGROUPS, 1)
+        Hf.set_graph(True)
+        for step in range(2):
+            st.timestep7_fused(U, DT)
+            st.timestep7_fused(Hf, DT)
+            _same_bits(U, Hf, f"half workgroups under graph replay, step {step}")
     U.close()
     Hf.close()
 

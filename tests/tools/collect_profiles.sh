@@ -10,6 +10,8 @@ for f in hbm_traffic_pmc_tierA.json hbm_traffic_pmc_tierB.json hbm_traffic_pmc_f
          hbm_traffic_pmc_soil_tierB.json hbm_traffic_pmc_fused_f32_tierA.json hbm_traffic_pmc_fused_f32_tierB.json compute_pmc_tierA.json compute_pmc_tierB.json compute_pmc_tierA.txt compute_pmc_tierB.txt bench_1M.json bench_1M_rocprof_kernel_stats.csv bench_1M_fused_rocprof_kernel_stats.csv \
          hbm_traffic_pmc_10M_tierA.json hbm_traffic_pmc_10M_tierB.json hbm_traffic_pmc_10M_fused_tierA.json hbm_traffic_pmc_10M_fused_tierB.json \
          hbm_traffic_pmc_10M_fused_f32_tierA.json hbm_traffic_pmc_10M_fused_f32_tierB.json bench_10M_rocprof_kernel_stats.csv bench_10M_fused_rocprof_kernel_stats.csv \
+         compute_pmc_fused_tierA.json compute_pmc_fused_tierB.json compute_pmc_10M_tierA.json compute_pmc_10M_tierB.json compute_pmc_10M_fused_tierA.json compute_pmc_10M_fused_tierB.json \
+         compute_pmc_fused_tierA.txt compute_pmc_fused_tierB.txt compute_pmc_10M_tierA.txt compute_pmc_10M_tierB.txt compute_pmc_10M_fused_tierA.txt compute_pmc_10M_fused_tierB.txt \
          bench_soil_10M.json bench_soil_1M.json advance_times_1M.txt bench_2ranks_on_1gpu.json device_info.txt; do
   [ -f $O/$f ] && cp $O/$f profiles/${P}_$f
 done

@@ -25,6 +25,8 @@ doc = {
             "per-launch means over the settled launches (the first three launches of every kernel run without scheduling hints and are "
             "left out).  SQ_ACTIVE_INST_VALU is in units of 4 cycles summed over waves, GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
     "source_hash": bench.kernel_source_hash(),
+    "columns": cols,
+    "tier": tier,
     "kernels": {},
 }
 for name, ctr in sorted(acc.items()):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag> [pmc|pmc10|bench|rest|all]
+# GPU box: the measurements DESIGN.md and profiles/ quote.  bash tests/tools/profile_round.sh <tag> [pmc|pmc10|sq|bench|rest|all]
 # (outputs under gpurun_out/<tag>/; tests/tools/collect_profiles.sh copies the files to commit into profiles/ with the round
 # prefix.  One gpurun call is limited to 20 minutes, so a round is four calls - pmc, pmc10, then bench, then rest - with a
 # collect_profiles.sh after the first: the benchmark reads the PMC tables from profiles/.)
@@ -67,6 +67,19 @@ for mode in "" "--fused"; do
   cp $O/kt/p_kernel_stats.csv $O/${n}_rocprof_kernel_stats.csv
   cp $O/${n}_rocprof_kernel_stats.csv $R/profiles/${P}_${n}_rocprof_kernel_stats.csv
   rm -rf $O/kt
+done
+fi
+if [ $STAGE = sq ] || [ $STAGE = all ]; then
+# 1d. the compute side beyond the per-wrapper step at 1 M columns: the fused step's kernels at 1 M, and both steps at 10 M (VERDICT r03 missing #4)
+for spec in "1000000 fused fused_" "10000000 timestep7 10M_" "10000000 fused 10M_fused_"; do
+  set -- $spec; cols=$1; mode=$2; pre=$3
+  for tier in A B; do
+    rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_lane -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py $cols $tier $mode > $O/pmc_lane_${pre}$tier.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 -d $O/pmc_f64 -o p --output-format csv -- python3 $R/tests/tools/traffic_probe.py $cols $tier $mode > $O/pmc_f64_${pre}$tier.log 2>&1
+    python3 $R/tests/tools/make_compute_json.py $O/compute_pmc_${pre}tier$tier.json $cols $tier $O/pmc_lane $O/pmc_f64 | tee $O/compute_pmc_${pre}tier$tier.txt
+    cp $O/compute_pmc_${pre}tier$tier.json $R/profiles/${P}_compute_pmc_${pre}tier$tier.json
+    rm -rf $O/pmc_lane $O/pmc_f64
+  done
 done
 fi
 if [ $STAGE = bench ] || [ $STAGE = all ]; then
